@@ -1,0 +1,100 @@
+/*
+ * nerfdet_hip.h -- C ABI of libnerfdet_hip.so: the MI355X (gfx950) implementation of the
+ * NeRF-Det volumetric hot path.
+ *
+ * The reference has no FFI layer on this path (it is pure PyTorch Python); the drop-in boundary
+ * is the set of module-level Python callables listed in SURVEY.md section 8(b).  Every entry
+ * point below states which reference callable (file:line under the reference tree) it replaces.
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the parameter name ends in _host;
+ *   - fp32 everywhere on the data path, int64 for counts / indices (as the reference);
+ *   - caller allocates every output; the library allocates nothing and keeps no state
+ *     between calls (re-entrant; one process per GPU);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); work is only enqueued,
+ *     never synchronised;
+ *   - return value: 0 on success, negative NDET_E_* otherwise; ndet_last_error() gives a
+ *     thread-local message.  The Python mirror turns these into the exceptions the reference
+ *     raises (AssertionError / ValueError).
+ */
+#ifndef NERFDET_HIP_H
+#define NERFDET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDET_OK 0
+#define NDET_E_INVALID (-1)     /* bad argument (null pointer, non-positive size) */
+#define NDET_E_UNSUPPORTED (-2) /* shape outside what the kernels are built for */
+#define NDET_E_LAUNCH (-3)      /* hipLaunch / runtime failure */
+
+#define NDET_LAYOUT_CN 0 /* (C, N): the reference's (C,X,Y,Z) contiguous layout */
+#define NDET_LAYOUT_NC 1 /* (N, C): channels-last (NDHWC), the native layout of this library */
+
+int ndet_version(void);
+const char* ndet_last_error(void);
+
+/* A2. Voxel lower-corner lattice. Replaces get_points(), mmdet3d/models/detectors/nerfdet.py:380-390.
+ * points: (3, nx*ny*nz) fp32, z fastest.  voxel_size_host/origin_host: 3 floats each, HOST memory.
+ * Same fp32 operation order as the reference: idx*vs + (origin - n/2*vs), un-fused. */
+int ndet_get_points(float* points, int nx, int ny, int nz, const float* voxel_size_host,
+                    const float* origin_host, void* stream);
+
+/* Layout helper: (n, c, hw) -> (n, hw, c).  The reference keeps feature maps NCHW; the fused kernels
+ * want one pixel's channels contiguous (SURVEY.md section 7 "Layout").  No reference counterpart. */
+int ndet_nchw_to_nhwc(const float* src, float* dst, int n, int c, int hw, void* stream);
+
+/* A3 (exact API form). Replaces backproject(), nerfdet.py:393-420 (depth=None).
+ * features: element (v,c,y,x) at v*sv + c*sc + y*sy + x*sx (floats) -- any layout.
+ * points (3,N); projection (n_views,3,4).  Outputs the reference's materialised tensors:
+ * volume (n_views, C, N) fp32 (zero where invalid) and valid (n_views, N) uint8 0/1. */
+int ndet_backproject(const float* features, int n_views, int C, int h, int w,
+                     int64_t sv, int64_t sc, int64_t sy, int64_t sx,
+                     const float* points, int N, const float* projection,
+                     float* volume, uint8_t* valid, void* stream);
+
+/* A3+A4 (+A6 gating) fused -- the inference hot kernel.  Replaces backproject() followed by the view
+ * aggregation of nerfdet.py:171-176 and, when alpha != NULL, the gating of nerfdet.py:259-261, without
+ * materialising the (n_views,C,N) volume.
+ * features_nhwc: element (v,y,x,c) at v*view_pitch + y*row_pitch + x*C + c (floats); C % 4 == 0, C <= 1024.
+ * alpha: NULL or (N) fp32.  out: mean (or alpha*mean) in `out_layout`; count: (N) int64 view count. */
+int ndet_backproject_aggregate(const float* features_nhwc, int n_views, int C, int h, int w,
+                               int64_t view_pitch, int64_t row_pitch,
+                               const float* points, int N, const float* projection,
+                               const float* alpha, float* out, int out_layout, int64_t* count,
+                               void* stream);
+
+/* A5. Per-voxel NeRF conditioning vector.  Replaces nerfdet.py:234-253 (image mode) with the algebraic
+ * identity mapping(volume)[v] == mapped_map[v,y,x] where the view sees the voxel and == bias where it
+ * does not.
+ * mapped_nhwc: Linear(C->cm)(features), element (v,y,x,c) at v*mview_pitch + y*mrow_pitch + x*cm + c; cm <= 61.
+ * bias: (cm) the Linear's bias.  rgb: de-normalised images, element (v,c,y,x) at v*rsv + c*rsc + y*rsy + x
+ * (3 channels, H x W).  projection: stride-4 matrices (validity + count), rgb_projection: stride-1 matrices.
+ * global_feat: (N, 2*(3+cm)) fp32, channels INTERLEAVED [mean_0,cov_0,mean_1,cov_1,...] with channel order
+ * [rgb0,rgb1,rgb2,m0..m(cm-1)] -- the effective layout of the reference's cat(dim=1)+view (nerfdet.py:251-253). */
+int ndet_density_features(const float* mapped_nhwc, int n_views, int cm, int h, int w,
+                          int64_t mview_pitch, int64_t mrow_pitch, const float* bias,
+                          const float* rgb, int H, int W, int64_t rsv, int64_t rsc, int64_t rsy,
+                          const float* points, int N, const float* projection, const float* rgb_projection,
+                          float* global_feat, void* stream);
+
+/* A6 (gating only, unfused form). volume = (1-exp(-density)) * mean, 0 where count==0; nerfdet.py:257-261.
+ * mean/out in `layout` with C channels. */
+int ndet_alpha_gate(const float* mean, const float* density, const int64_t* count, float* out,
+                    int C, int N, int layout, void* stream);
+
+/* alpha = 1 - exp(-relu(raw_sigma)) for N voxels (nerf_mlp.py:227 + nerfdet.py:257). */
+int ndet_sigma_to_alpha(const float* raw_sigma, float* alpha, int N, void* stream);
+
+/* A6 input assembly: rows [posenc(xyz) (63) | global (F)] for the sigma-MLP, nerf_mlp.py:181-197,140.
+ * points (3,N) SoA; out (N, 63+F). */
+int ndet_posenc_concat(const float* points, const float* global_feat, int N, int F, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFDET_HIP_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of libnerfdet_hip.so (the C ABI declared in include/nerfdet_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing the import of any compute
+entry point raises -- a silent PyTorch path would void every parity and performance claim.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnerfdet_hip.so")
+
+NDET_LAYOUT_CN = 0
+NDET_LAYOUT_NC = 1
+
+_P = c_void_p
+_F3 = ctypes.POINTER(c_float)
+
+# name -> argtypes; kept in one table so tests can check the .so exports exactly this surface
+SIGNATURES = {
+    "ndet_version": ([], c_int),
+    "ndet_last_error": ([], c_char_p),
+    "ndet_get_points": ([_P, c_int, c_int, c_int, _F3, _F3, _P], c_int),
+    "ndet_nchw_to_nhwc": ([_P, _P, c_int, c_int, c_int, _P], c_int),
+    "ndet_backproject": ([_P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, _P, c_int, _P, _P, _P, _P], c_int),
+    "ndet_backproject_aggregate": ([_P, c_int, c_int, c_int, c_int, c_int64, c_int64, _P, c_int, _P, _P, _P, c_int, _P, _P], c_int),
+    "ndet_density_features": ([_P, c_int, c_int, c_int, c_int, c_int64, c_int64, _P, _P, c_int, c_int, c_int64, c_int64,
+                               c_int64, _P, c_int, _P, _P, _P, _P], c_int),
+    "ndet_alpha_gate": ([_P, _P, _P, _P, c_int, c_int, c_int, _P], c_int),
+    "ndet_sigma_to_alpha": ([_P, _P, c_int, _P], c_int),
+    "ndet_posenc_concat": ([_P, _P, c_int, c_int, _P, _P], c_int),
+}
+
+_lib = None
+
+
+class NdetError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C nerf-det_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    """0 -> ok.  NDET_E_INVALID maps to AssertionError (the reference asserts on bad arguments),
+    NDET_E_UNSUPPORTED to ValueError, anything else to NdetError."""
+    if code == 0:
+        return
+    msg = load().ndet_last_error().decode("utf-8", "replace")
+    if code == -1:
+        raise AssertionError(f"{what}: {msg}")
+    if code == -2:
+        raise ValueError(f"{what}: {msg}")
+    raise NdetError(f"{what}: error {code}: {msg}")
+
+
+def float3(vals):
+    return (c_float * 3)(*[float(v) for v in vals])

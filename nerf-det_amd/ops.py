@@ -1,0 +1,227 @@
+"""Host-side mirror of the reference's module-level hot-path callables,
+bodies routed to libnerfdet_hip.so through the C ABI.  PyTorch is used for device memory and
+streams only; every function here requires CUDA(HIP) tensors and raises otherwise.
+
+Reference signatures kept: ``get_points``, ``backproject`` (mmdet3d/models/detectors/nerfdet.py:380-420).
+Fused forms that have no single reference counterpart (``backproject_aggregate``, ``density_features``)
+document the reference lines they replace.
+"""
+from __future__ import annotations
+
+from ctypes import c_void_p
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import NDET_LAYOUT_CN, NDET_LAYOUT_NC, check, float3
+
+Tensor = torch.Tensor
+
+
+def _ptr(t: Optional[Tensor]):
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(t: Tensor):
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need_gpu(*ts: Tensor):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("nerfdet_amd.ops: tensors must live on the GPU (no CPU fallback in the product path)")
+
+
+def _f32c(t: Tensor) -> Tensor:
+    return t.to(torch.float32).contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# A1
+# --------------------------------------------------------------------------------------------
+def compute_projection(img_meta: dict, stride: int, device=None) -> Tensor:
+    """(n_views,3,4) pixel projections ``K' @ E[:3]`` (nerfdet.py:363-378, angles=None).
+
+    50 3x4 matrices: built on the host in the reference's fp32 op order, one H2D copy."""
+    k = torch.tensor(np.asarray(img_meta["lidar2img"]["intrinsic"], dtype=np.float32)[:3, :3])
+    k[:2] /= img_meta["ori_shape"][0] / (img_meta["img_shape"][0] / stride)
+    ext = torch.from_numpy(np.stack([np.asarray(e, dtype=np.float32) for e in img_meta["lidar2img"]["extrinsic"]]))
+    proj = torch.stack([k @ e[:3] for e in ext])
+    return proj.to(device) if device is not None else proj
+
+
+# --------------------------------------------------------------------------------------------
+# A2
+# --------------------------------------------------------------------------------------------
+def get_points(n_voxels, voxel_size, origin, device=None) -> Tensor:
+    """Voxel lower-corner lattice (3,X,Y,Z) fp32 on the GPU.  nerfdet.py:380-390."""
+    nv = [int(v) for v in (n_voxels.tolist() if isinstance(n_voxels, Tensor) else n_voxels)]
+    vs = [float(v) for v in (voxel_size.tolist() if isinstance(voxel_size, Tensor) else voxel_size)]
+    org = origin.tolist() if isinstance(origin, (Tensor, np.ndarray)) else list(origin)
+    assert len(nv) == 3 and len(vs) == 3 and len(org) == 3
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if dev.type != "cuda":
+        raise RuntimeError("nerfdet_amd.ops.get_points: device must be a GPU")
+    pts = torch.empty((3, nv[0], nv[1], nv[2]), dtype=torch.float32, device=dev)
+    check(_lib.load().ndet_get_points(_ptr(pts), nv[0], nv[1], nv[2], float3(np.float32(vs)), float3(np.float32(org)),
+                                      _stream(pts)), "get_points")
+    return pts
+
+
+# --------------------------------------------------------------------------------------------
+# layout
+# --------------------------------------------------------------------------------------------
+def to_channels_last(x: Tensor) -> Tensor:
+    """(n,C,h,w) logical tensor -> same logical tensor whose memory is (n,h,w,C) (torch channels_last).
+
+    A tensor that already has unit channel stride and x-stride == C is returned as is (also when it is
+    an [:h,:w] crop of a larger channels-last map); a contiguous NCHW one goes through the HIP transpose."""
+    _need_gpu(x)
+    n, c, h, w = x.shape
+    if x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(3) == c and x.stride(2) % 4 == 0 and x.stride(0) % 4 == 0 \
+            and x.data_ptr() % 16 == 0:
+        return x
+    if x.dtype == torch.float32 and x.is_contiguous():
+        out = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+        check(_lib.load().ndet_nchw_to_nhwc(_ptr(x), _ptr(out), n, c, h * w, _stream(x)), "nchw_to_nhwc")
+        return out.permute(0, 3, 1, 2)
+    return to_channels_last(_f32c(x))
+
+
+# --------------------------------------------------------------------------------------------
+# A3 exact form
+# --------------------------------------------------------------------------------------------
+def backproject(features: Tensor, points: Tensor, projection: Tensor, depth=None, voxel_size=None) -> Tuple[Tensor, Tensor]:
+    """Reference API: (n_v,C,h,w),(3,X,Y,Z),(n_v,3,4) -> volume (n_v,C,X,Y,Z), valid (n_v,1,X,Y,Z) bool.
+    nerfdet.py:393-420.  Materialises the per-view volume exactly like the reference; the inference
+    path uses :func:`backproject_aggregate` instead.  ``depth`` gating is dead code under every shipped
+    config and is rejected."""
+    assert depth is None, "depth-gated backproject (nerfdet.py:405-411) is not reachable from the nerfdet configs"
+    _need_gpu(features, points, projection)
+    if features.dtype != torch.float32:
+        features = features.float()
+    n_v, c, h, w = features.shape
+    gx, gy, gz = points.shape[-3:]
+    n = gx * gy * gz
+    points = _f32c(points)
+    projection = _f32c(projection)
+    assert projection.shape == (n_v, 3, 4)
+    volume = torch.empty((n_v, c, gx, gy, gz), dtype=torch.float32, device=features.device)
+    valid = torch.empty((n_v, 1, gx, gy, gz), dtype=torch.bool, device=features.device)
+    sv, sc, sy, sx = features.stride()
+    check(_lib.load().ndet_backproject(_ptr(features), n_v, c, h, w, sv, sc, sy, sx, _ptr(points), n, _ptr(projection),
+                                       _ptr(volume), _ptr(valid), _stream(features)), "backproject")
+    return volume, valid
+
+
+# --------------------------------------------------------------------------------------------
+# K1: A3 + A4 (+ A6 gating)
+# --------------------------------------------------------------------------------------------
+def backproject_aggregate(features: Tensor, points: Tensor, projection: Tensor, alpha: Optional[Tensor] = None,
+                          channels_last_out: bool = True) -> Tuple[Tensor, Tensor]:
+    """Fused ``backproject`` + view mean/count of nerfdet.py:164-176 (and, with ``alpha``, the gating of
+    nerfdet.py:259-261): returns ``(volume (C,X,Y,Z), count (1,X,Y,Z) int64)``.
+
+    ``features`` is the logical (n_v,C,h,w) map, ideally channels-last in memory.  With
+    ``channels_last_out`` the result's memory is (X,Y,Z,C) -- what a channels-last 3D conv wants -- while
+    its logical shape stays the reference's (C,X,Y,Z)."""
+    _need_gpu(features, points, projection, alpha)
+    f = to_channels_last(features)
+    n_v, c, h, w = f.shape
+    gx, gy, gz = points.shape[-3:]
+    n = gx * gy * gz
+    points = _f32c(points)
+    projection = _f32c(projection)
+    assert projection.shape == (n_v, 3, 4)
+    if alpha is not None:
+        alpha = _f32c(alpha).reshape(-1)
+        assert alpha.numel() == n
+    count = torch.empty((1, gx, gy, gz), dtype=torch.int64, device=f.device)
+    if channels_last_out:
+        buf = torch.empty((gx, gy, gz, c), dtype=torch.float32, device=f.device)
+        out, layout = buf.permute(3, 0, 1, 2), NDET_LAYOUT_NC
+    else:
+        buf = torch.empty((c, gx, gy, gz), dtype=torch.float32, device=f.device)
+        out, layout = buf, NDET_LAYOUT_CN
+    check(_lib.load().ndet_backproject_aggregate(_ptr(f), n_v, c, h, w, f.stride(0), f.stride(2), _ptr(points), n,
+                                                 _ptr(projection), _ptr(alpha), _ptr(buf), layout, _ptr(count),
+                                                 _stream(f)), "backproject_aggregate")
+    return out, count
+
+
+# --------------------------------------------------------------------------------------------
+# K2: A5
+# --------------------------------------------------------------------------------------------
+def density_features(mapped: Tensor, bias: Tensor, denorm_images: Tensor, points: Tensor, projection: Tensor,
+                     rgb_projection: Tensor) -> Tensor:
+    """(N, 2*(3+cm)) NeRF conditioning rows for the voxel grid; replaces nerfdet.py:234-253.
+
+    ``mapped``: logical (n_v,cm,h,w) = Linear(C->cm) of the feature map (``feature_2d`` of nerfdet.py:194-197),
+    ``bias`` its bias (contributed by views that do not see a voxel), ``denorm_images`` (n_v,3,H,W)."""
+    _need_gpu(mapped, bias, denorm_images, points, projection, rgb_projection)
+    m = to_channels_last(mapped)
+    n_v, cm, h, w = m.shape
+    rgb = denorm_images if denorm_images.dtype == torch.float32 else denorm_images.float()
+    assert rgb.shape[0] == n_v and rgb.shape[1] == 3
+    if rgb.stride(3) != 1:
+        rgb = rgb.contiguous()
+    hh, ww = rgb.shape[2:]
+    n = points.shape[-3] * points.shape[-2] * points.shape[-1]
+    points, projection, rgb_projection, bias = _f32c(points), _f32c(projection), _f32c(rgb_projection), _f32c(bias)
+    out = torch.empty((n, 2 * (3 + cm)), dtype=torch.float32, device=m.device)
+    check(_lib.load().ndet_density_features(_ptr(m), n_v, cm, h, w, m.stride(0), m.stride(2), _ptr(bias), _ptr(rgb), hh, ww,
+                                            rgb.stride(0), rgb.stride(1), rgb.stride(2), _ptr(points), n, _ptr(projection),
+                                            _ptr(rgb_projection), _ptr(out), _stream(m)), "density_features")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# A6 pieces
+# --------------------------------------------------------------------------------------------
+def sigma_to_alpha(raw_sigma: Tensor) -> Tensor:
+    """``1 - exp(-relu(raw_sigma))`` (nerf_mlp.py:227, nerfdet.py:257)."""
+    _need_gpu(raw_sigma)
+    r = _f32c(raw_sigma).reshape(-1)
+    out = torch.empty_like(r)
+    check(_lib.load().ndet_sigma_to_alpha(_ptr(r), _ptr(out), r.numel(), _stream(r)), "sigma_to_alpha")
+    return out
+
+
+def alpha_gate(mean: Tensor, density: Tensor, count: Tensor) -> Tensor:
+    """Unfused gating of nerfdet.py:257-261: ``(1-exp(-density)) * mean`` zeroed where count == 0.
+    ``mean`` (C,X,Y,Z) contiguous or channels-last (as produced by :func:`backproject_aggregate`)."""
+    _need_gpu(mean, density, count)
+    c = mean.shape[0]
+    n = mean[0].numel()
+    if mean.is_contiguous():
+        layout, out = NDET_LAYOUT_CN, torch.empty_like(mean)
+        src = mean
+    else:
+        src = mean.permute(1, 2, 3, 0)
+        if not src.is_contiguous():
+            return alpha_gate(mean.contiguous(), density, count)
+        layout = NDET_LAYOUT_NC
+        out = torch.empty_like(src).permute(3, 0, 1, 2)
+    density = _f32c(density).reshape(-1)
+    count = count.to(torch.int64).contiguous().reshape(-1)
+    assert density.numel() == n and count.numel() == n
+    check(_lib.load().ndet_alpha_gate(_ptr(src), _ptr(density), _ptr(count), _ptr(out), c, n, layout, _stream(mean)), "alpha_gate")
+    return out
+
+
+def posenc_concat(points: Tensor, global_feat: Optional[Tensor]) -> Tensor:
+    """Input rows of the sigma-MLP: ``[posenc_10(xyz) (63) | global_feat]`` (nerf_mlp.py:181-197,140).
+    ``points`` (3,X,Y,Z) or (3,N)."""
+    _need_gpu(points, global_feat)
+    p = _f32c(points).reshape(3, -1)
+    n = p.shape[1]
+    f = 0
+    if global_feat is not None:
+        global_feat = _f32c(global_feat)
+        assert global_feat.shape[0] == n
+        f = global_feat.shape[1]
+    out = torch.empty((n, 63 + f), dtype=torch.float32, device=p.device)
+    check(_lib.load().ndet_posenc_concat(_ptr(p), _ptr(global_feat), n, f, _ptr(out), _stream(p)), "posenc_concat")
+    return out

@@ -1,0 +1,60 @@
+"""The fused inference pipeline of the hot path: FPN level-0 features -> gated voxel volume.
+
+Replaces steps 2-11 of ``nerfdet.extract_feat`` (mmdet3d/models/detectors/nerfdet.py:152-261, image
+mode, nerf_density=True).  The reference materialises a (n_views, C, N) volume and passes over it
+five times; here nothing larger than the inputs and the outputs ever exists:
+
+    mapped  = Linear(C->cm)(features)            library GEMM, (n_v,h,w,cm) channels-last
+    glob    = K2 density_features(mapped, rgb)   (N, 2*(3+cm))
+    alpha   = 1-exp(-relu(sigma_MLP([posenc|glob])))
+    volume, count = K1 backproject_aggregate(features, alpha)   gating fused into the aggregation
+
+The order differs from the reference (density first, aggregation last) so that the alpha gating
+costs no extra pass over the (C, N) volume; the arithmetic per element is the reference's.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+Tensor = torch.Tensor
+
+
+def map_features_2d(features: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
+    """``self.mapping`` on every feature pixel (nerfdet.py:194-197).  Logical (n_v,cm,h,w), channels-last
+    memory -- with channels-last ``features`` this is a single GEMM on a view, no permute copies."""
+    f = ops.to_channels_last(features)
+    rows = f.permute(0, 2, 3, 1)  # (n_v,h,w,C) view
+    if not rows.is_contiguous():  # an [:h,:w] crop of a padded map
+        rows = rows.contiguous()
+    return F.linear(rows, weight, bias).permute(0, 3, 1, 2)
+
+
+def extract_volume(features: Tensor, denorm_images: Tensor, img_meta: dict, n_voxels, voxel_size,
+                   mapping: torch.nn.Module, nerf_mlp, stride: int = 4, channels_last_out: bool = True,
+                   feature_2d: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """One scene.  ``features`` (n_v,C,Hf,Wf) FPN level 0 (channels-last preferred), ``denorm_images``
+    (n_v,3,H,W).  Returns ``volume`` (C,X,Y,Z) = alpha * mean (zero where unseen), ``valid`` (1,X,Y,Z) int64
+    view count, plus ``feature_2d`` (the mapped map, reused by the ray branch) and ``density``."""
+    dev = features.device
+    h = img_meta["img_shape"][0] // stride
+    w = img_meta["img_shape"][1] // stride
+    feat = ops.to_channels_last(features)[:, :, :h, :w]
+    proj = ops.compute_projection(img_meta, stride, dev)
+    rgb_proj = ops.compute_projection(img_meta, 1, dev)
+    pts = ops.get_points(n_voxels, voxel_size, img_meta["lidar2img"]["origin"], dev)
+    lin = mapping[0] if isinstance(mapping, torch.nn.Sequential) else mapping
+    if feature_2d is None:
+        feature_2d = map_features_2d(feat, lin.weight, lin.bias)
+    rgb = denorm_images[:, :, :img_meta["img_shape"][0], :img_meta["img_shape"][1]]
+    glob = ops.density_features(feature_2d, lin.bias, rgb, pts, proj, rgb_proj)
+    rows = ops.posenc_concat(pts, glob)
+    raw_sigma = nerf_mlp.raw_sigma_from_rows(rows)
+    alpha = ops.sigma_to_alpha(raw_sigma)
+    volume, count = ops.backproject_aggregate(feat, pts, proj, alpha=alpha, channels_last_out=channels_last_out)
+    return dict(volume=volume, valid=count, feature_2d=feature_2d, global_feat=glob, raw_sigma=raw_sigma,
+                alpha=alpha, points=pts, projection=proj, rgb_projection=rgb_proj)

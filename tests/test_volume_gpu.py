@@ -1,0 +1,228 @@
+"""GPU parity tests (through the C ABI) for the voxel-grid side of the hot path: A1-A6.
+
+Tolerances: indices / counts / validity bit-exact (outside the measure-zero set of voxel-views whose
+projected coordinate lies within 1e-3 px of a rounding boundary -- those are *reported* and must stay
+below 1 % of the voxels); voxel features <= 1e-4 absolute fp32 as BASELINE.json's north_star states
+(the tests use 2e-5, tighter)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_meta, load_golden, sub_state
+from oracle import nerfdet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 2e-5  # north_star allows 1e-4
+
+
+def _ops():
+    import nerfdet_amd.ops as ops
+    return ops
+
+
+def near_boundary_voxels(points, proj, w, h, tol=1e-3):
+    """voxels with at least one view whose pixel coordinate is within `tol` of a .5 rounding boundary
+    (or whose depth is ~0): the only places where a 1-ulp difference in the projection may flip an index."""
+    u, v, d = O.project_voxels(points, proj)
+    fu, fv = u - torch.floor(u), v - torch.floor(v)
+    near = ((fu - 0.5).abs() < tol) | ((fv - 0.5).abs() < tol) | (d.abs() < 1e-6)
+    inside = (u > -1) & (u < w) & (v > -1) & (v < h)
+    return (near & inside).any(dim=0)
+
+
+def rand_scene(n_v, c, img_hw, n_voxels, voxel_size, seed=0, origin=(0, 0, 0.5)):
+    g = torch.Generator().manual_seed(seed)
+    meta = O.ring_scene_meta(n_v, img_hw, origin=origin)
+    feats = torch.randn(n_v, c, img_hw[0] // 4, img_hw[1] // 4, generator=g)
+    rgb = torch.rand(n_v, 3, *img_hw, generator=g)
+    return meta, feats, rgb
+
+
+# ------------------------------------------------------------------------------------------------
+def test_get_points_bit_exact(device):
+    ops = _ops()
+    for nv, vs, org in [((40, 40, 16), (0.16, 0.16, 0.2), (0.0, 0.0, 0.5)), ((7, 5, 3), (0.3, 0.11, 0.7), (1.3, -2.2, 0.37)),
+                        ((80, 80, 32), (0.16, 0.16, 0.2), (0.7, -0.7, 0.5))]:
+        ref = O.get_points(nv, vs, np.asarray(org, dtype=np.float32))
+        got = ops.get_points(nv, vs, np.asarray(org, dtype=np.float32), device)
+        assert torch.equal(got.cpu(), ref)
+
+
+def test_nchw_to_nhwc(device):
+    ops = _ops()
+    x = torch.randn(3, 37, 9, 13, device=device)
+    y = ops.to_channels_last(x)
+    assert y.shape == x.shape and y.stride(1) == 1
+    assert torch.equal(y, x)
+
+
+@pytest.mark.parametrize("name", ["volume_small_s0", "volume_small_s1", "volume_medium_s2"])
+def test_backproject_reference_api_matches_golden(device, name):
+    """ops.backproject == the reference's backproject() on the golden inputs (NCHW and channels-last)."""
+    ops = _ops()
+    g = load_golden(name)
+    meta = golden_meta(g)
+    h, w = meta["img_shape"][0] // 4, meta["img_shape"][1] // 4
+    pts, proj = g["points"].to(device), g["projection"].to(device)
+    for cl in (False, True):
+        f = g["features"].to(device)
+        if cl:
+            f = f.contiguous(memory_format=torch.channels_last)
+        vol, valid = ops.backproject(f[:, :, :h, :w], pts, proj, None, None)
+        assert valid.dtype == torch.bool and torch.equal(valid.cpu(), g["bp_valid"])
+        assert torch.equal(vol[0].cpu(), g["bp_volume_v0"]) and torch.equal(vol[-1].cpu(), g["bp_volume_vlast"])
+        torch.testing.assert_close(vol.sum(0).cpu(), g["bp_volume_sum"], rtol=0, atol=ATOL)
+    with pytest.raises(AssertionError):
+        ops.backproject(f, pts, proj, depth=torch.zeros(1, device=device))
+
+
+@pytest.mark.parametrize("name", ["volume_small_s0", "volume_small_s1", "volume_medium_s2"])
+@pytest.mark.parametrize("cl_out", [True, False])
+def test_backproject_aggregate_vs_oracle(device, name, cl_out):
+    ops = _ops()
+    g = load_golden(name)
+    meta = golden_meta(g)
+    h, w = meta["img_shape"][0] // 4, meta["img_shape"][1] // 4
+    vol, valid = O.backproject(g["features"][:, :, :h, :w], g["points"], g["projection"])
+    mean, cnt, _ = O.aggregate_views(vol, valid)
+    f = g["features"].to(device).contiguous(memory_format=torch.channels_last)[:, :, :h, :w]
+    got, gcnt = ops.backproject_aggregate(f, g["points"].to(device), g["projection"].to(device), None, cl_out)
+    assert gcnt.dtype == torch.int64 and torch.equal(gcnt.cpu(), cnt)
+    assert got.shape == mean.shape
+    torch.testing.assert_close(got.cpu(), mean, rtol=0, atol=ATOL)
+    # gated form: alpha * mean, zero where unseen
+    alpha = torch.rand(cnt.numel())
+    got2, _ = ops.backproject_aggregate(f, g["points"].to(device), g["projection"].to(device), alpha.to(device), cl_out)
+    exp = alpha.view(1, *mean.shape[1:]) * mean
+    exp[:, cnt[0] == 0] = 0
+    torch.testing.assert_close(got2.cpu(), exp, rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("name", ["volume_small_s0", "volume_small_s1", "volume_medium_s2"])
+def test_density_features_vs_oracle(device, name):
+    ops = _ops()
+    from nerfdet_amd.volume import map_features_2d
+    g = load_golden(name)
+    meta = golden_meta(g)
+    h, w = meta["img_shape"][0] // 4, meta["img_shape"][1] // 4
+    H, W = meta["img_shape"][:2]
+    vol, valid = O.backproject(g["features"][:, :, :h, :w], g["points"], g["projection"])
+    cnt = valid.sum(0)
+    rvol, _ = O.backproject(g["denorm_images"][:, :, :H, :W], g["points"], g["rgb_projection"])
+    ref = O.density_features(vol, rvol, cnt, g["mapping.0.weight"], g["mapping.0.bias"])
+    f = g["features"].to(device).contiguous(memory_format=torch.channels_last)[:, :, :h, :w]
+    mapped = map_features_2d(f, g["mapping.0.weight"].to(device), g["mapping.0.bias"].to(device))
+    torch.testing.assert_close(mapped.cpu(), O.map_features_2d(g["features"][:, :, :h, :w], g["mapping.0.weight"], g["mapping.0.bias"]),
+                               rtol=1e-5, atol=1e-5)
+    got = ops.density_features(mapped, g["mapping.0.bias"].to(device), g["denorm_images"].to(device)[:, :, :H, :W],
+                               g["points"].to(device), g["projection"].to(device), g["rgb_projection"].to(device)).cpu()
+    seen = (cnt.reshape(-1) > 0)
+    assert seen.float().mean() > 0.3
+    torch.testing.assert_close(got[seen], ref[seen], rtol=1e-5, atol=ATOL)
+    # unseen voxels: mean = n_v*b/1e-8 (huge, later zeroed by the gate), cov = exp(-1e6) = 0  (nerfdet.py:241,249)
+    torch.testing.assert_close(got[~seen], ref[~seen], rtol=1e-5, atol=ATOL)
+
+
+@pytest.mark.parametrize("name", ["volume_small_s0", "volume_small_s1", "volume_medium_s2"])
+def test_extract_volume_matches_reference_golden(device, name):
+    """Whole A1-A6 chain on the GPU == the real reference's nerfdet.extract_feat output (golden)."""
+    from nerfdet_amd.nerf_mlp import VanillaNeRFRadianceField
+    from nerfdet_amd.volume import extract_volume
+    g = load_golden(name)
+    meta = golden_meta(g)
+    sd = sub_state(g, "nerf_mlp.")
+    width = sd["mlp.base.hidden_layers.0.weight"].shape[0]
+    fdim = sd["mlp.base.hidden_layers.0.weight"].shape[1] - 63
+    mlp = VanillaNeRFRadianceField(4, width, 3, fdim, 1, width // 2)
+    mlp.load_state_dict(sd)
+    mlp.to(device).eval()
+    mapping = torch.nn.Sequential(torch.nn.Linear(g["mapping.0.weight"].shape[1], g["mapping.0.weight"].shape[0]))
+    mapping.load_state_dict(sub_state(g, "mapping."))
+    mapping.to(device)
+    with torch.no_grad():
+        for cl in (True, False):
+            f = g["features"].to(device)
+            if cl:
+                f = f.contiguous(memory_format=torch.channels_last)
+            out = extract_volume(f, g["denorm_images"].to(device), meta, g["n_voxels"].tolist(), g["voxel_size"].tolist(),
+                                 mapping, mlp, channels_last_out=cl)
+            assert torch.equal(out["valid"].cpu(), g["out_valid"])
+            torch.testing.assert_close(out["volume"].cpu(), g["out_volume"], rtol=0, atol=ATOL)
+
+
+def test_cfg2_full_size_vs_oracle_and_properties(device):
+    """BASELINE configs[1] shape: 50 views, 256 ch, 60x80 features, 40x40x16 voxels."""
+    ops = _ops()
+    n_v, c = 50, 256
+    meta, feats, rgb = rand_scene(n_v, c, (240, 320), (40, 40, 16), (0.16, 0.16, 0.2))
+    proj = O.compute_projection(meta, 4)
+    pts = O.get_points((40, 40, 16), (0.16, 0.16, 0.2), meta["lidar2img"]["origin"])
+    vol, valid = O.backproject(feats, pts, proj)
+    mean, cnt, _ = O.aggregate_views(vol, valid)
+    del vol
+    f = feats.to(device).contiguous(memory_format=torch.channels_last)
+    dp, dj = pts.to(device), proj.to(device)
+    got, gcnt = ops.backproject_aggregate(f, dp, dj)
+    excl = near_boundary_voxels(pts, proj, 80, 60)
+    frac = valid.float().mean().item()
+    assert 0.2 < frac < 0.45, frac
+    bad = (gcnt.cpu() != cnt).reshape(-1)
+    assert not (bad & ~excl).any(), "view count differs away from rounding boundaries"
+    assert excl.float().mean() < 0.05
+    ok = ~(bad | excl)
+    diff = (got.cpu() - mean).reshape(c, -1)[:, ok].abs().max().item()
+    assert diff <= ATOL, diff
+    print(f"cfg2: valid fraction {frac:.3f}, boundary voxels {int(excl.sum())}, count mismatches {int(bad.sum())}, max|d|={diff:.2e}")
+    # size-independent properties at full size
+    got_cn, _ = ops.backproject_aggregate(f, dp, dj, None, False)
+    assert torch.equal(got_cn, got)                                  # both output layouts agree bit for bit
+    got2, _ = ops.backproject_aggregate(2.0 * f, dp, dj)
+    assert torch.equal(got2, 2.0 * got)                               # linear in the features (exact: x2)
+    perm = torch.randperm(n_v)
+    gotp, cntp = ops.backproject_aggregate(f[perm.to(device)].contiguous(memory_format=torch.channels_last), dp, dj[perm.to(device)])
+    assert torch.equal(cntp, gcnt)                                    # count is invariant to view order
+    torch.testing.assert_close(gotp, got, rtol=0, atol=ATOL)          # mean up to summation order
+    assert int(gcnt.max()) <= n_v and int(gcnt.min()) >= 0
+    assert (got[:, gcnt[0] == 0] == 0).all()
+    ones, _ = ops.backproject_aggregate(torch.ones_like(f), dp, dj)
+    assert torch.equal(ones[0] != 0, gcnt[0] > 0)
+    torch.testing.assert_close(ones[:, gcnt[0] > 0], torch.ones_like(ones[:, gcnt[0] > 0]), rtol=0, atol=1e-6)
+
+
+def test_edge_cases(device):
+    ops = _ops()
+    # a grid no camera sees: everything zero, count zero
+    meta, feats, _ = rand_scene(4, 8, (32, 48), (4, 4, 2), (0.1, 0.1, 0.1), origin=(50.0, 50.0, -30.0))
+    proj = O.compute_projection(meta, 4).to(device)
+    pts = ops.get_points((4, 4, 2), (0.1, 0.1, 0.1), meta["lidar2img"]["origin"], device)
+    vol, cnt = ops.backproject_aggregate(feats.to(device), pts, proj)
+    ovol, ovalid = O.backproject(feats, pts.cpu(), proj.cpu())
+    assert torch.equal(cnt.cpu(), ovalid.sum(0))
+    if int(cnt.sum()) == 0:
+        assert (vol == 0).all()
+    # ragged sizes: N not a multiple of the 16-voxel tile, single view, C not a multiple of 256
+    meta, feats, _ = rand_scene(1, 12, (20, 28), (3, 5, 7), (0.5, 0.4, 0.3))
+    proj = O.compute_projection(meta, 4)
+    pts = O.get_points((3, 5, 7), (0.5, 0.4, 0.3), meta["lidar2img"]["origin"])
+    ovol, ovalid = O.backproject(feats, pts, proj)
+    mean, ocnt, _ = O.aggregate_views(ovol, ovalid)
+    for cl in (True, False):
+        vol, cnt = ops.backproject_aggregate(feats.to(device), pts.to(device), proj.to(device), None, cl)
+        assert torch.equal(cnt.cpu(), ocnt)
+        torch.testing.assert_close(vol.cpu(), mean, rtol=0, atol=ATOL)
+    # 101 views: two 64-view rounds
+    meta, feats, _ = rand_scene(101, 16, (40, 56), (6, 6, 4), (0.8, 0.8, 0.6), seed=3)
+    proj = O.compute_projection(meta, 4)
+    pts = O.get_points((6, 6, 4), (0.8, 0.8, 0.6), meta["lidar2img"]["origin"])
+    ovol, ovalid = O.backproject(feats, pts, proj)
+    mean, ocnt, _ = O.aggregate_views(ovol, ovalid)
+    vol, cnt = ops.backproject_aggregate(feats.to(device), pts.to(device), proj.to(device))
+    assert int(ocnt.max()) > 64
+    assert torch.equal(cnt.cpu(), ocnt)
+    torch.testing.assert_close(vol.cpu(), mean, rtol=0, atol=ATOL)
+    # bad arguments raise like the reference's asserts
+    with pytest.raises(ValueError):
+        ops.backproject_aggregate(torch.randn(2, 6, 5, 7, device=device), pts.to(device), proj[:2].to(device))  # C % 4 != 0
+    with pytest.raises(RuntimeError):
+        ops.backproject_aggregate(feats, pts, proj)  # CPU tensors: no fallback
