@@ -67,6 +67,7 @@ def cpu_baseline(w, mapping, mlp, repeats=3):
     """The oracle (PyTorch-CPU restatement of the reference, materialised volume and all) on the host cores."""
     from oracle import nerfdet_oracle as O
     cores = os.cpu_count() or 1
+    cores = min(cores, 32)  # measured on the GPU box: 16-32 threads is the knee, 256 is 50x slower
     torch.set_num_threads(cores)
     meta, feats, rgb = synth_scene(w, 0, "cpu")
     wt, bs = mapping[0].weight.detach().cpu(), mapping[0].bias.detach().cpu()

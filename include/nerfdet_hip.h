@@ -94,6 +94,16 @@ int ndet_sigma_to_alpha(const float* raw_sigma, float* alpha, int N, void* strea
  * points (3,N) SoA; out (N, 63+F). */
 int ndet_posenc_concat(const float* points, const float* global_feat, int N, int F, float* out, void* stream);
 
+/* A15. Greedy class-aware axis-aligned 3D NMS. Replaces aligned_3d_nms(),
+ * mmdet3d/core/post_processing/box3d_nms.py:91-138 (pinned by the reference's tests/test_nms.py:5-58).
+ * boxes (n,6) x1,y1,z1,x2,y2,z2; scores (n); classes (n) int64; n <= 4096.
+ * keep: (n) int64, receives the picked ORIGINAL indices in pick order (highest score first);
+ * n_keep: (1) int64 device scalar.  workspace: ndet_nms_workspace_bytes(n) bytes of device memory.
+ * Score ties (undefined in the reference: torch.argsort is unstable) are taken higher index first. */
+int64_t ndet_nms_workspace_bytes(int n);
+int ndet_aligned_3d_nms(const float* boxes, const float* scores, const int64_t* classes, int n, float thresh,
+                        int64_t* keep, int64_t* n_keep, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,150 @@
+"""2D backbone + FPN in plain PyTorch-ROCm (vendor-library convolutions: MIOpen).
+
+mmdet 2.10.0's ``ResNet`` and ``FPN`` are third-party and absent from the reference tree; these are
+restatements of their documented behaviour with the same state-dict key names
+(torchvision-layout ``conv1/bn1/layer{1-4}.{i}.{conv,bn}{1-3}/downsample.{0,1}``;
+``lateral_convs.{i}.conv`` / ``fpn_convs.{i}.conv``) so torchvision / released checkpoints load.
+Not part of the hand-written hot path; they feed it channels-last features."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .registry import BACKBONES, NECKS
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)  # style='pytorch': stride on the 3x3
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        out = F.relu(self.bn2(self.conv2(out)), inplace=True)
+        out = self.bn3(self.conv3(out))
+        return F.relu(out + idt, inplace=True)
+
+
+@BACKBONES.register_module()
+class ResNet(nn.Module):
+    arch = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+    def __init__(self, depth, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1, norm_cfg=None, norm_eval=True,
+                 style="pytorch", **kw):
+        super().__init__()
+        assert style == "pytorch" and depth in self.arch
+        self.out_indices, self.frozen_stages, self.norm_eval = tuple(out_indices), frozen_stages, norm_eval
+        self.bn_requires_grad = True if norm_cfg is None else norm_cfg.get("requires_grad", True)
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        inplanes = 64
+        for i, n in enumerate(self.arch[depth][:num_stages]):
+            planes, stride = 64 * 2 ** i, 1 if i == 0 else 2
+            blocks = []
+            for b in range(n):
+                ds = None
+                if b == 0 and (stride != 1 or inplanes != planes * 4):
+                    ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+                blocks.append(Bottleneck(inplanes, planes, stride if b == 0 else 1, ds))
+                inplanes = planes * 4
+            setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
+        self.num_stages = num_stages
+        if not self.bn_requires_grad:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    for p in m.parameters():
+                        p.requires_grad = False
+        self._freeze()
+
+    def _freeze(self):
+        if self.frozen_stages >= 0:
+            for m in (self.conv1, self.bn1):
+                m.eval()
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f"layer{i}")
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def init_weights(self, pretrained=None):
+        """``torchvision://resnet50`` is a network fetch (unavailable offline); a local path loads."""
+        if isinstance(pretrained, str) and not pretrained.startswith(("torchvision://", "http")):
+            sd = torch.load(pretrained, map_location="cpu")
+            self.load_state_dict(sd.get("state_dict", sd), strict=False)
+            return
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        return self
+
+    def forward(self, x):
+        x = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        x = F.max_pool2d(x, 3, 2, 1)
+        outs = []
+        for i in range(self.num_stages):
+            x = getattr(self, f"layer{i + 1}")(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+
+class _Conv(nn.Module):
+    """mmcv ``ConvModule`` without norm/activation: keeps the ``.conv`` key level."""
+
+    def __init__(self, cin, cout, k, padding=0):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=padding)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+@NECKS.register_module()
+class FPN(nn.Module):
+    """1x1 laterals, top-down nearest upsample-add, 3x3 output convs; no extra levels when
+    num_outs == len(in_channels).  ``active_outs`` lets the detector skip output convs whose result it
+    drops (nerfdet.py:142 keeps level 0 only) -- same numerics for the kept level."""
+
+    def __init__(self, in_channels, out_channels, num_outs, **kw):
+        super().__init__()
+        assert num_outs == len(in_channels), "extra FPN levels are not used by the nerfdet configs"
+        self.in_channels, self.out_channels, self.num_outs = list(in_channels), out_channels, num_outs
+        self.lateral_convs = nn.ModuleList(_Conv(c, out_channels, 1) for c in in_channels)
+        self.fpn_convs = nn.ModuleList(_Conv(out_channels, out_channels, 3, 1) for _ in in_channels)
+        self.active_outs = None  # None = all
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def forward(self, inputs):
+        lat = [l(x) for l, x in zip(self.lateral_convs, inputs)]
+        for i in range(len(lat) - 1, 0, -1):
+            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest")
+        act = range(len(lat)) if self.active_outs is None else self.active_outs
+        return tuple(self.fpn_convs[i](lat[i]) if i in act else None for i in range(len(lat)))

@@ -1,0 +1,149 @@
+// A15: greedy class-aware axis-aligned 3D NMS with the reference's pick order
+// (mmdet3d/core/post_processing/box3d_nms.py:91-138), n <= 4096 candidates (the head feeds <= 3000).
+//
+//   1. k_nms_sort      one workgroup: bitonic sort of (score, index) in LDS -> `order`, highest score first
+//                      (the reference argsorts ascending and pops from the back; ties resolved by higher
+//                      index first here -- torch.argsort is unstable, so the reference leaves ties undefined).
+//   2. k_nms_mask      n x ceil(n/64) suppression bit matrix over the sorted list: bit (i, j) set when
+//                      picking i removes j, i.e. NOT (iou_ij * [class_i == class_j] <= thresh).  NaN IoU
+//                      (0/0 on zero-volume pairs) fails the <= and removes, exactly as the reference.
+//   3. k_nms_sweep     one wavefront walks the sorted list; the removed-set lives in one 64-bit word per lane,
+//                      rows are prefetched 8 deep so the walk is not latency bound.
+#include "ndet_common.hpp"
+
+#define NMS_MAX 4096
+
+__global__ __launch_bounds__(1024) void k_nms_sort(const float* __restrict__ scores, int n, int* __restrict__ order) {
+    __shared__ float key[NMS_MAX];
+    __shared__ int idx[NMS_MAX];
+    int m = 1;
+    while (m < n) m <<= 1;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        key[i] = i < n ? scores[i] : -__builtin_inff();
+        idx[i] = i < n ? i : -1;
+    }
+    __syncthreads();
+    // descending by (score, index); padding (-inf, -1) sinks to the end
+    for (int k = 2; k <= m; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < m; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const float a = key[i], b = key[p];
+                    const int ia = idx[i], ib = idx[p];
+                    // "a before b" in the final descending order?
+                    const bool a_first = (a > b) || (a == b && ia > ib) || (b != b && a == a);
+                    const bool desc = ((i & k) == 0);
+                    if (desc ? !a_first : a_first) {
+                        key[i] = b; key[p] = a;
+                        idx[i] = ib; idx[p] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) order[i] = idx[i];
+}
+
+__device__ __forceinline__ float box_volume(const float* b) { return (b[3] - b[0]) * (b[4] - b[1]) * (b[5] - b[2]); }
+
+__global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, const int64_t* __restrict__ classes,
+                                                 const int* __restrict__ order, int n, float thresh,
+                                                 unsigned long long* __restrict__ mask) {
+    // block (bx, by): rows 64*by.., columns 64*bx.. of the sorted list
+    const int words = (n + 63) / 64;
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb) return;  // only j > i matters
+    __shared__ float cbox[64][6];
+    __shared__ long long ccls[64];
+    const int cj = cb * 64 + threadIdx.x;
+    if (cj < n) {
+        const int o = order[cj];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cbox[threadIdx.x][k] = boxes[o * 6 + k];
+        ccls[threadIdx.x] = classes[o];
+    }
+    __syncthreads();
+    const int i = rb * 64 + threadIdx.x;
+    if (i >= n) return;
+    const int oi = order[i];
+    float bi[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bi[k] = boxes[oi * 6 + k];
+    const long long ci = classes[oi];
+    const float ai = box_volume(bi);
+    unsigned long long bits = 0ull;
+    const int jn = min(64, n - cb * 64);
+    for (int t = 0; t < jn; ++t) {
+        const int j = cb * 64 + t;
+        if (j <= i) continue;
+        const float* bj = cbox[t];
+        const float l = fmaxf(0.0f, fminf(bi[3], bj[3]) - fmaxf(bi[0], bj[0]));
+        const float w = fmaxf(0.0f, fminf(bi[4], bj[4]) - fmaxf(bi[1], bj[1]));
+        const float h = fmaxf(0.0f, fminf(bi[5], bj[5]) - fmaxf(bi[2], bj[2]));
+        const float inter = l * w * h;
+        float iou = inter / (ai + box_volume(bj) - inter);
+        iou = iou * (ci == ccls[t] ? 1.0f : 0.0f);
+        if (!(iou <= thresh)) bits |= 1ull << t;
+    }
+    mask[(int64_t)i * words + cb] = bits;
+}
+
+__global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long* __restrict__ mask, const int* __restrict__ order,
+                                                  int n, int64_t* __restrict__ keep, int64_t* __restrict__ n_keep) {
+    const int lane = threadIdx.x;
+    const int words = (n + 63) / 64;  // <= 64
+    unsigned long long removed = 0ull;  // lane w holds bits [64w, 64w+64)
+    constexpr int PF = 8;
+    unsigned long long row[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) row[k] = (k < n && lane < words && lane >= k / 64) ? mask[(int64_t)k * words + lane] : 0ull;
+    int kept = 0;
+    for (int i0 = 0; i0 < n; i0 += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int i = i0 + k;
+            if (i < n) {
+                const unsigned long long wsel = __shfl(removed, i >> 6);
+                const bool gone = (wsel >> (i & 63)) & 1ull;
+                if (!gone) {
+                    if (lane == 0) keep[kept] = (int64_t)order[i];
+                    ++kept;
+                    removed |= row[k];
+                }
+            }
+            const int nx = i + PF;  // refill this slot; words left of the diagonal were never written -> skip them
+            row[k] = (nx < n && lane < words && lane >= nx / 64) ? mask[(int64_t)nx * words + lane] : 0ull;
+        }
+    }
+    if (lane == 0) *n_keep = kept;
+}
+
+extern "C" int64_t ndet_nms_workspace_bytes(int n) {
+    if (n <= 0) return 0;
+    const size_t words = (size_t)(n + 63) / 64;
+    return (int64_t)((size_t)n * words * 8 + (size_t)n * 4 + 64);
+}
+
+extern "C" int ndet_aligned_3d_nms(const float* boxes, const float* scores, const int64_t* classes, int n, float thresh,
+                                   int64_t* keep, int64_t* n_keep, void* workspace, void* stream) {
+    const char* fn = "ndet_aligned_3d_nms";
+    NDET_REQUIRE(n_keep && (n == 0 || (boxes && scores && classes && keep && workspace)), NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(n >= 0, NDET_E_INVALID, "%s: negative n", fn);
+    NDET_REQUIRE(n <= NMS_MAX, NDET_E_UNSUPPORTED, "%s: n=%d candidates, at most %d supported", fn, n, NMS_MAX);
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(n_keep, 0, sizeof(int64_t), st);
+        NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: memset failed", fn);
+        return NDET_OK;
+    }
+    const int words = (n + 63) / 64;
+    unsigned long long* mask = (unsigned long long*)workspace;
+    int* order = (int*)((char*)workspace + (size_t)n * words * 8);
+    hipLaunchKernelGGL(k_nms_sort, dim3(1), dim3(1024), 0, st, scores, n, order);
+    hipLaunchKernelGGL(k_nms_mask, dim3(words, words), dim3(64), 0, st, boxes, classes, order, n, thresh, mask);
+    hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, st, mask, order, n, keep, n_keep);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}

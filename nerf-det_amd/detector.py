@@ -1,0 +1,192 @@
+"""``nerfdet`` detector: mirror of mmdet3d/models/detectors/nerfdet.py:13-361 with the volumetric hot
+path routed through the HIP kernels.  Same registry name, constructor keys, method names, batch-dict
+keys and return structures, so ``configs/nerfdet/*.py`` build it unmodified."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import ops
+from .boxes import DepthInstance3DBoxes, bbox3d2result
+from .nerf_mlp import VanillaNeRFRadianceField
+from .registry import DETECTORS, build_backbone, build_head, build_neck
+from .volume import extract_volume
+
+
+class BaseDetector(nn.Module):
+    """The slice of mmdet's BaseDetector the path uses: ``forward(return_loss=...)`` dispatch and
+    ``train_step`` / ``_parse_losses``."""
+
+    def init_weights(self, pretrained=None):
+        pass
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        return self.forward_test(img, img_metas, **kwargs)
+
+    @staticmethod
+    def _parse_losses(losses):
+        import torch.distributed as dist
+        log = {}
+        for k, v in losses.items():
+            log[k] = v.mean() if isinstance(v, torch.Tensor) else sum(x.mean() for x in v)
+        loss = sum(v for k, v in log.items() if "loss" in k)
+        log["loss"] = loss
+        out = {}
+        for k, v in log.items():
+            v = v.detach().clone()
+            if dist.is_available() and dist.is_initialized():
+                dist.all_reduce(v.div_(dist.get_world_size()))
+            out[k] = v.item()
+        return loss, out
+
+    def train_step(self, data, optimizer=None):
+        loss, log_vars = self._parse_losses(self(**data))
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data["img_metas"]))
+
+
+@DETECTORS.register_module()
+class nerfdet(BaseDetector):
+    def __init__(self, backbone, neck, neck_3d, bbox_head, n_voxels, voxel_size, head_2d=None, train_cfg=None,
+                 test_cfg=None, pretrained=None, aabb=None, near_far_range=None, N_samples=40, N_rand=4096,
+                 depth_supervise=False, use_nerf_mask=True, nerf_sample_view=3, nerf_mode="volume", squeeze_scale=4,
+                 rgb_supervision=True, nerf_density=False, render_testing=False):
+        super().__init__()
+        assert head_2d is None, "head_2d (SUN RGB-D layout head) is not used by any nerfdet config (nerfdet.py:46)"
+        self.backbone = build_backbone(backbone)
+        self.neck = build_neck(neck)
+        self.neck_3d = build_neck(neck_3d)
+        bbox_head = dict(bbox_head)
+        bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)
+        self.bbox_head = build_head(bbox_head)
+        self.bbox_head.voxel_size = voxel_size
+        self.head_2d = None
+        self.n_voxels, self.voxel_size = n_voxels, voxel_size
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.aabb, self.near_far_range = aabb, near_far_range
+        self.N_samples, self.N_rand = N_samples, N_rand
+        self.depth_supervise, self.use_nerf_mask, self.rgb_supervision = depth_supervise, use_nerf_mask, rgb_supervision
+        self.squeeze_scale, self.nerf_mode = squeeze_scale, nerf_mode
+        self.nerf_density, self.nerf_sample_view, self.render_testing = nerf_density, nerf_sample_view, render_testing
+        c = neck["out_channels"]
+        fd = c // squeeze_scale
+        self.nerf_mlp = VanillaNeRFRadianceField(net_depth=4, net_width=256, skip_layer=3, feature_dim=fd + 6,
+                                                 net_depth_condition=1, net_width_condition=128)
+        # parameters the reference constructs but never uses in nerf_mode="image" (nerfdet.py:77-111): kept
+        # so released checkpoints load key-for-key
+        self.cov = nn.Sequential(nn.Conv3d(c, c, 3, padding=1), nn.ReLU(inplace=True), nn.Conv3d(c, c, 3, padding=1),
+                                 nn.ReLU(inplace=True), nn.Conv3d(c, 1, 1))
+        self.mean_mapping = nn.Sequential(nn.Conv3d(c, fd // 2, 1))
+        self.cov_mapping = nn.Sequential(nn.Conv3d(c, fd // 2, 1))
+        self.mapping = nn.Sequential(nn.Linear(c, fd // 2))
+        self.mapping_2d = nn.Sequential(nn.Conv2d(c, fd // 2, 1))
+        self.init_weights(pretrained=pretrained)
+        # MI355X: 2D convs run channels-last (MIOpen NHWC), so FPN level 0 arrives in the layout the
+        # gather kernels want; only FPN output 0 is consumed (nerfdet.py:142)
+        self.backbone.to(memory_format=torch.channels_last)
+        self.neck.to(memory_format=torch.channels_last)
+        if hasattr(self.neck, "active_outs"):
+            self.neck.active_outs = (0,)
+
+    def init_weights(self, pretrained=None):
+        super().init_weights(pretrained)
+        self.backbone.init_weights(pretrained=pretrained)
+        self.neck.init_weights()
+        self.neck_3d.init_weights()
+        self.bbox_head.init_weights()
+
+    # ---------------------------------------------------------------------------------------
+    def extract_2d(self, img):
+        """(B,n_v,3,H,W) -> FPN level 0 (B,n_v,C,H/4,W/4), channels-last memory (nerfdet.py:134-147)."""
+        b = img.shape[0]
+        x = img.reshape([-1] + list(img.shape)[2:]).contiguous(memory_format=torch.channels_last)
+        x = self.neck(self.backbone(x))[0]
+        stride = img.shape[-1] / x.shape[-1]
+        assert stride == 4
+        return x, b, int(stride)
+
+    def extract_feat(self, img, img_metas, mode, depth=None, ray_batch=None):
+        """Same contract as nerfdet.py:133-269: returns (neck_3d outputs, valids, features_2d, rgb_preds, densitys)."""
+        assert depth is None, "depth is never forwarded to extract_feat by the reference (SURVEY.md 0.1)"
+        assert ray_batch is not None and self.nerf_density and self.nerf_mode == "image", \
+            "effective contract of the reference: use_ray=True, nerf_density=True, nerf_mode='image' (SURVEY.md 0.2)"
+        x, batch, stride = self.extract_2d(img)
+        n_v = x.shape[0] // batch
+        denorm = ray_batch["denorm_images"]
+        volumes, valids, rgb_preds = [], [], []
+        for b, img_meta in enumerate(img_metas):
+            feat = x[b * n_v:(b + 1) * n_v]
+            dn = denorm.reshape([-1] + list(denorm.shape)[2:])
+            out = extract_volume(feat, dn, img_meta, self.n_voxels, self.voxel_size, self.mapping, self.nerf_mlp,
+                                 stride=stride, channels_last_out=False)
+            if mode == "train" or self.render_testing:
+                from .rays import render_rays
+                rgb_preds.append(render_rays(ray_batch, None, None, out["feature_2d"], dn, self.aabb, self.near_far_range,
+                                             self.N_samples, self.N_rand, self.nerf_mlp, img_meta, None, self.nerf_mode,
+                                             self.nerf_sample_view, is_train=(mode == "train"),
+                                             render_testing=self.render_testing))
+            else:
+                rgb_preds.append(None)  # render_ray.py:518-519
+            volumes.append(out["volume"])
+            valids.append(out["valid"])
+        x3 = volumes[0].unsqueeze(0) if len(volumes) == 1 else torch.stack(volumes)
+        valids = valids[0].unsqueeze(0) if len(valids) == 1 else torch.stack(valids)
+        return self.neck_3d(x3), valids, None, rgb_preds, []
+
+    @staticmethod
+    def _ray_batch(kwargs):
+        rb = {}
+        if "raydirs" in kwargs:
+            rb = dict(ray_o=kwargs["lightpos"], ray_d=kwargs["raydirs"], gt_rgb=kwargs["gt_images"],
+                      gt_depth=kwargs["gt_depths"], nerf_sizes=kwargs["nerf_sizes"], denorm_images=kwargs["denorm_images"])
+        return rb
+
+    def forward_train(self, img, img_metas, gt_bboxes_3d, gt_labels_3d, **kwargs):
+        rb = self._ray_batch(kwargs)
+        x, valids, _, rgb_preds, _ = self.extract_feat(img, img_metas, "train", ray_batch=rb or None)
+        losses = self.bbox_head.forward_train(x, valids.float(), img_metas, gt_bboxes_3d, gt_labels_3d)
+        if rb and self.rgb_supervision:
+            losses.update(self.nvs_loss_func(rgb_preds))
+        if self.depth_supervise:
+            losses.update(self.depth_loss_func(rgb_preds))
+        return losses
+
+    def nvs_loss_func(self, rgb_pred):
+        loss = 0
+        for ret in rgb_pred:
+            rgb, gt, m = ret["outputs_coarse"]["rgb"], ret["gt_rgb"], ret["outputs_coarse"]["mask"]
+            loss = loss + (torch.sum(m.unsqueeze(-1) * (rgb - gt) ** 2) / (m.sum() + 1e-6) if self.use_nerf_mask
+                           else torch.mean((rgb - gt) ** 2))
+        return dict(loss_nvs=loss)
+
+    def depth_loss_func(self, rgb_pred):
+        loss = 0
+        for ret in rgb_pred:
+            d, gt, m = ret["outputs_coarse"]["depth"], ret["gt_depth"].squeeze(-1), ret["outputs_coarse"]["mask"]
+            loss = loss + (torch.sum(m * torch.abs(d - gt)) / (m.sum() + 1e-6) if self.use_nerf_mask
+                           else torch.mean(torch.abs(d - gt)))
+        return dict(loss_depth=loss)
+
+    def forward_test(self, img, img_metas, **kwargs):
+        rb = self._ray_batch(kwargs)
+        return self.simple_test(img, img_metas, ray_batch=rb or None)
+
+    def simple_test(self, img, img_metas, depth=None, ray_batch=None, evaluate_nerf=False):
+        x, valids, _, _, _ = self.extract_feat(img, img_metas, "test", depth, ray_batch)
+        outs = self.bbox_head(x)
+        for m in img_metas:
+            m.setdefault("box_type_3d", DepthInstance3DBoxes)
+        bbox_list = self.bbox_head.get_bboxes(*outs, valids.float(), img_metas)
+        return [bbox3d2result(b, s, l) for b, s, l in bbox_list]
+
+    def aug_test(self, imgs, img_metas):
+        pass
+
+    def show_results(self, *args, **kwargs):
+        pass
+
+    @staticmethod
+    def _compute_projection(img_meta, stride, angles=None):
+        assert angles is None
+        return ops.compute_projection(img_meta, stride)

@@ -1,0 +1,223 @@
+"""A14 / A16: ``ScanNetImVoxelHeadV2`` mirror (mmdet3d/models/dense_heads/imvoxel_head_v2.py:12-300,
+442-566): FCOS-style anchor-free 3D head over the three neck levels.  Same constructor keys, state-dict
+keys (``centerness_conv``, ``reg_conv``, ``cls_conv``, ``scales.N.scale``) and outputs.
+
+Inference post-processing runs on the GPU: lattice points from the HIP ``get_points`` kernel, greedy NMS
+from csrc/nms_kernels.hip (identical pick order to the reference's Python loop)."""
+from __future__ import annotations
+
+import math
+from typing import List
+
+import torch
+from torch import nn
+
+from . import ops
+from .nms import aligned_3d_nms
+from .registry import HEADS, build_loss
+
+
+class Scale(nn.Module):
+    """mmcv.cnn.Scale: learnable scalar multiply."""
+
+    def __init__(self, scale: float = 1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+    def forward(self, x):
+        return x * self.scale
+
+
+def compute_centerness(t):
+    """imvoxel_head_v2.py:558-566: sqrt of the product of min/max ratios per axis."""
+    x, y, z = t[..., [0, 1]], t[..., [2, 3]], t[..., [4, 5]]
+    c = x.min(dim=-1)[0] / x.max(dim=-1)[0] * y.min(dim=-1)[0] / y.max(dim=-1)[0] * z.min(dim=-1)[0] / z.max(dim=-1)[0]
+    return torch.sqrt(c)
+
+
+def _dist_to_box(points, d):
+    """(x-,x+,y-,y+,z-,z+) distances from `points` -> (x1,y1,z1,x2,y2,z2).  imvoxel_head_v2.py:547-555."""
+    return torch.stack([points[:, 0] - d[:, 0], points[:, 1] - d[:, 2], points[:, 2] - d[:, 4],
+                        points[:, 0] + d[:, 1], points[:, 1] + d[:, 3], points[:, 2] + d[:, 5]], -1)
+
+
+@HEADS.register_module()
+class ScanNetImVoxelHeadV2(nn.Module):
+    def __init__(self, n_classes, n_channels, n_reg_outs, n_scales, limit, centerness_topk=-1,
+                 loss_centerness=dict(type="CrossEntropyLoss", use_sigmoid=True, loss_weight=1.0),
+                 loss_bbox=dict(type="AxisAlignedIoULoss", loss_weight=1.0),
+                 loss_cls=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                 train_cfg=None, test_cfg=None):
+        super().__init__()
+        self.n_classes, self.n_scales, self.limit, self.centerness_topk = n_classes, n_scales, limit, centerness_topk
+        self.loss_centerness = build_loss(loss_centerness)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.loss_cls = build_loss(loss_cls)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.voxel_size = None  # set by the detector (nerfdet.py:45)
+        self.centerness_conv = nn.Conv3d(n_channels, 1, 3, padding=1, bias=False)
+        self.reg_conv = nn.Conv3d(n_channels, n_reg_outs, 3, padding=1, bias=False)
+        self.cls_conv = nn.Conv3d(n_channels, n_classes, 3, padding=1)
+        self.scales = nn.ModuleList([Scale(1.0) for _ in range(n_scales)])
+
+    def init_weights(self):
+        """N(0, .01) weights, class bias = -log((1-p)/p) at p = .01 (imvoxel_head_v2.py:52-55)."""
+        for m in (self.centerness_conv, self.reg_conv, self.cls_conv):
+            nn.init.normal_(m.weight, 0.0, 0.01)
+        nn.init.constant_(self.cls_conv.bias, float(-math.log((1 - 0.01) / 0.01)))
+
+    # ---- forward ---------------------------------------------------------------------------
+    def forward_single(self, x, scale):
+        return self.centerness_conv(x), torch.exp(scale(self.reg_conv(x))), self.cls_conv(x)
+
+    def forward(self, x):
+        outs = [self.forward_single(f, s) for f, s in zip(x, self.scales)]
+        return tuple(map(list, zip(*outs)))
+
+    def forward_train(self, x, valid, img_metas, gt_bboxes, gt_labels):
+        return self.loss(*(self(x) + (valid, img_metas, gt_bboxes, gt_labels)))
+
+    @torch.no_grad()
+    def get_points(self, featmap_sizes, origin, device):
+        """Per-level lattice with voxel_size * 2^i (imvoxel_head_v2.py:205-214), (n_i, 3) each."""
+        out = []
+        for i, size in enumerate(featmap_sizes):
+            vs = torch.tensor(self.voxel_size) * (2 ** i)
+            out.append(ops.get_points(list(size), vs, origin, device).reshape(3, -1).transpose(0, 1))
+        return out
+
+    def _level_valids(self, centernesses, valid):
+        return [nn.functional.interpolate(valid, size=x.shape[-3:], mode="trilinear").round().bool() for x in centernesses]
+
+    # ---- inference -------------------------------------------------------------------------
+    def get_bboxes(self, centernesses, bbox_preds, cls_scores, valid, img_metas):
+        assert len(centernesses[0]) == len(bbox_preds[0]) == len(cls_scores[0]) == len(img_metas)
+        valids = self._level_valids(centernesses, valid)
+        res = []
+        for b in range(len(img_metas)):
+            res.append(self._get_bboxes_single([x[b].detach() for x in centernesses], [x[b].detach() for x in bbox_preds],
+                                               [x[b].detach() for x in cls_scores], [x[b].detach() for x in valids],
+                                               img_metas[b]))
+        return res
+
+    def _candidates(self, centernesses, bbox_preds, cls_scores, valids, img_meta):
+        """Per-level sigmoid scores * centerness * valid, top ``nms_pre`` per level, decoded boxes
+        (imvoxel_head_v2.py:248-282)."""
+        sizes = [f.size()[-3:] for f in centernesses]
+        pts_l = self.get_points(sizes, img_meta["lidar2img"]["origin"], centernesses[0].device)
+        boxes, scores = [], []
+        for ctr, reg, cls, val, pts in zip(centernesses, bbox_preds, cls_scores, valids, pts_l):
+            ctr = ctr.permute(1, 2, 3, 0).reshape(-1).sigmoid()
+            reg = reg.permute(1, 2, 3, 0).reshape(-1, reg.shape[0])
+            sc = cls.permute(1, 2, 3, 0).reshape(-1, self.n_classes).sigmoid()
+            sc = sc * ctr[:, None] * val.permute(1, 2, 3, 0).reshape(-1)[:, None]
+            if len(sc) > self.test_cfg.nms_pre > 0:
+                _, ids = sc.max(dim=1)[0].topk(self.test_cfg.nms_pre)
+                reg, sc, pts = reg[ids], sc[ids], pts[ids]
+            boxes.append(_dist_to_box(pts, reg))
+            scores.append(sc)
+        return torch.cat(boxes), torch.cat(scores)
+
+    def _get_bboxes_single(self, centernesses, bbox_preds, cls_scores, valids, img_meta):
+        boxes, scores = self._candidates(centernesses, bbox_preds, cls_scores, valids, img_meta)
+        return self._nms(boxes, scores, img_meta)
+
+    def _nms(self, bboxes, scores, img_meta):
+        """class argmax, score threshold, greedy aligned NMS, corner -> (centre, size) (imvoxel_head_v2.py:528-545)."""
+        scores, labels = scores.max(dim=1)
+        ids = scores > self.test_cfg.score_thr
+        bboxes, scores, labels = bboxes[ids], scores[ids], labels[ids]
+        ids = aligned_3d_nms(bboxes, scores, labels, self.test_cfg.iou_thr)
+        b = bboxes[ids]
+        b = torch.stack(((b[:, 0] + b[:, 3]) / 2.0, (b[:, 1] + b[:, 4]) / 2.0, (b[:, 2] + b[:, 5]) / 2.0,
+                         b[:, 3] - b[:, 0], b[:, 4] - b[:, 1], b[:, 5] - b[:, 2]), dim=1)
+        b = img_meta["box_type_3d"](b, origin=(0.5, 0.5, 0.5), box_dim=6, with_yaw=False)
+        return b, scores[ids], labels[ids]
+
+    # ---- training (A16) --------------------------------------------------------------------
+    def loss(self, centernesses, bbox_preds, cls_scores, valid, img_metas, gt_bboxes, gt_labels):
+        assert len(centernesses[0]) == len(valid) == len(img_metas) == len(gt_bboxes) == len(gt_labels)
+        valids = self._level_valids(centernesses, valid)
+        acc: List[List[torch.Tensor]] = [[], [], []]
+        for b in range(len(img_metas)):
+            ls = self._loss_single([x[b] for x in centernesses], [x[b] for x in bbox_preds], [x[b] for x in cls_scores],
+                                   [x[b] for x in valids], img_metas[b], gt_bboxes[b], gt_labels[b])
+            for a, l in zip(acc, ls):
+                a.append(l)
+        return dict(loss_centerness=torch.mean(torch.stack(acc[0])), loss_bbox=torch.mean(torch.stack(acc[1])),
+                    loss_cls=torch.mean(torch.stack(acc[2])))
+
+    def _loss_single(self, centernesses, bbox_preds, cls_scores, valids, img_meta, gt_bboxes, gt_labels):
+        """imvoxel_head_v2.py:116-203."""
+        dev = centernesses[0].device
+        pts_l = self.get_points([f.size()[-3:] for f in centernesses], img_meta["lidar2img"]["origin"], dev)
+        ctr_t, box_t, labels = self.get_targets(pts_l, gt_bboxes, gt_labels)
+        ctr = torch.cat([c.permute(1, 2, 3, 0).reshape(-1) for c in centernesses])
+        reg = torch.cat([r.permute(1, 2, 3, 0).reshape(-1, r.shape[0]) for r in bbox_preds])
+        cls = torch.cat([c.permute(1, 2, 3, 0).reshape(-1, self.n_classes) for c in cls_scores])
+        val = torch.cat([v.permute(1, 2, 3, 0).reshape(-1) for v in valids])
+        ctr_t, box_t, labels = ctr_t.to(dev), box_t.to(dev), labels.to(dev)
+        pts = torch.cat(pts_l)
+        pos = torch.nonzero(torch.logical_and(labels >= 0, val)).reshape(-1)
+        n_pos = torch.tensor(len(pos), dtype=torch.float, device=dev)
+        n_pos = max(_reduce_mean(n_pos), 1.0)
+        if torch.any(val):
+            loss_cls = self.loss_cls(cls[val], labels[val], avg_factor=n_pos)
+        else:
+            loss_cls = cls[val].sum()
+        if len(pos) > 0:
+            loss_ctr = self.loss_centerness(ctr[pos], ctr_t[pos], avg_factor=n_pos)
+            loss_box = self.loss_bbox(_dist_to_box(pts[pos], reg[pos]), box_t[pos], weight=ctr_t[pos],
+                                      avg_factor=ctr_t[pos].sum())
+        else:
+            loss_ctr, loss_box = ctr[pos].sum(), reg[pos].sum()
+        return loss_ctr, loss_box, loss_cls
+
+    @torch.no_grad()
+    def get_targets(self, points, gt_bboxes, gt_labels):
+        """FCOS-3D assignment of imvoxel_head_v2.py:457-526: a location is positive for a box when it is
+        inside it, sits on the box's best scale (first level with fewer than ``limit`` inside points,
+        minus one; last level if none), and is among the box's ``centerness_topk`` most central
+        locations; ties between boxes go to the smallest volume."""
+        big = 1e8
+        dev = gt_labels.device
+        lvl = torch.cat([p.new_tensor(i).expand(len(p)) for i, p in enumerate(points)]).to(dev)
+        pts = torch.cat(points, dim=0).to(dev)
+        n_pts, n_box = len(pts), len(gt_bboxes)
+        vol = gt_bboxes.volume.to(dev).expand(n_pts, n_box).contiguous()
+        gt = torch.cat((gt_bboxes.gravity_center, gt_bboxes.tensor[:, 3:6]), dim=1).to(dev).expand(n_pts, n_box, 6)
+        p = pts.unsqueeze(1).expand(n_pts, n_box, 3)
+        t = torch.stack((p[..., 0] - gt[..., 0] + gt[..., 3] / 2, gt[..., 0] + gt[..., 3] / 2 - p[..., 0],
+                         p[..., 1] - gt[..., 1] + gt[..., 4] / 2, gt[..., 1] + gt[..., 4] / 2 - p[..., 1],
+                         p[..., 2] - gt[..., 2] + gt[..., 5] / 2, gt[..., 2] + gt[..., 5] / 2 - p[..., 2]), dim=-1)
+        inside = t.min(-1)[0] > 0
+        per_scale = torch.stack([torch.sum(inside[lvl == i], dim=0) for i in range(self.n_scales)], dim=0)
+        low = per_scale < self.limit
+        rank = torch.arange(self.n_scales, 0, -1, device=dev).unsqueeze(1).expand(self.n_scales, n_box)
+        first_low = torch.argmax(low.int() * rank, dim=0) - 1
+        first_low = torch.where(first_low < 0, torch.zeros_like(first_low), first_low)
+        none_low = torch.all(torch.logical_not(low), dim=0)
+        best = torch.where(none_low, torch.ones_like(none_low) * self.n_scales - 1, first_low)
+        on_best = best.unsqueeze(0).expand(n_pts, n_box) == lvl.unsqueeze(1).expand(n_pts, n_box)
+        ctr = compute_centerness(t)
+        ctr = torch.where(inside, ctr, torch.ones_like(ctr) * -1)
+        ctr = torch.where(on_best, ctr, torch.ones_like(ctr) * -1)
+        kth = torch.topk(ctr, self.centerness_topk + 1, dim=0).values[-1]
+        central = ctr > kth.unsqueeze(0)
+        for m in (inside, on_best, central):
+            vol = torch.where(m, vol, torch.ones_like(vol) * big)
+        min_vol, arg = vol.min(dim=1)
+        labels = gt_labels[arg]
+        labels = torch.where(min_vol == big, torch.ones_like(labels) * -1, labels)
+        t = t[range(n_pts), arg]
+        return compute_centerness(t), _dist_to_box(pts, t), labels
+
+
+def _reduce_mean(t):
+    """mmdet.core.reduce_mean: identity unless distributed, else all-reduce(SUM) / world."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return t
+    t = t.clone()
+    dist.all_reduce(t.div_(dist.get_world_size()), op=dist.ReduceOp.SUM)
+    return t

@@ -1,0 +1,85 @@
+"""CPU checks of the registry/config surface: the reference's config files load unmodified and
+build the mirrored detector with the reference's state-dict surface."""
+import glob
+import os
+
+import pytest
+import torch
+
+REF_CFG = "/root/reference/configs/nerfdet"
+
+
+def test_preset_builds_with_reference_state_dict_surface():
+    from nerfdet_amd.presets import build_nerfdet
+    m = build_nerfdet(50)
+    sd = m.state_dict()
+    expect = {
+        "neck_3d.down_layer_0.0.conv1.weight": (256, 256, 3, 3, 3), "neck_3d.down_layer_1.0.conv1.weight": (512, 256, 3, 3, 3),
+        "neck_3d.down_layer_2.0.downsample.0.weight": (1024, 512, 1, 1, 1), "neck_3d.up_block_1.0.weight": (512, 256, 2, 2, 2),
+        "neck_3d.up_block_2.3.weight": (512, 512, 3, 3, 3), "neck_3d.out_block_2.0.weight": (128, 1024, 3, 3, 3),
+        "neck_3d.down_layer_0.0.norm1.num_batches_tracked": (),
+        "bbox_head.centerness_conv.weight": (1, 128, 3, 3, 3), "bbox_head.reg_conv.weight": (6, 128, 3, 3, 3),
+        "bbox_head.cls_conv.bias": (18,), "bbox_head.scales.2.scale": (),
+        "nerf_mlp.posi_encoder.scales": (10,), "nerf_mlp.mlp.base.hidden_layers.0.weight": (256, 133),
+        "nerf_mlp.mlp.sigma_layer.output_layer.weight": (1, 389), "nerf_mlp.mlp.bottleneck_layer.output_layer.weight": (256, 389),
+        "nerf_mlp.mlp.rgb_layer.hidden_layers.0.weight": (128, 283), "nerf_mlp.mlp.rgb_layer.output_layer.weight": (3, 128),
+        "mapping.0.weight": (32, 256), "cov.4.weight": (1, 256, 1, 1, 1), "mean_mapping.0.weight": (32, 256, 1, 1, 1),
+        "mapping_2d.0.weight": (32, 256, 1, 1),
+        "backbone.layer4.2.conv3.weight": (2048, 512, 1, 1), "backbone.layer1.0.downsample.0.weight": (256, 64, 1, 1),
+        "neck.lateral_convs.3.conv.weight": (256, 2048, 1, 1), "neck.fpn_convs.0.conv.bias": (256,),
+    }
+    for k, shape in expect.items():
+        assert k in sd, k
+        assert tuple(sd[k].shape) == shape, (k, tuple(sd[k].shape))
+    n_neck3d = sum(p.numel() for p in m.neck_3d.parameters())
+    assert n_neck3d == 77575936  # hook-counted on the real module
+    assert sum(p.numel() for p in m.nerf_mlp.parameters()) == 368649
+    # frozen stem + layer1, BN without grad (config:9-11)
+    assert not m.backbone.conv1.weight.requires_grad and not m.backbone.layer1[0].conv1.weight.requires_grad
+    assert m.backbone.layer2[0].conv1.weight.requires_grad and not m.backbone.layer2[0].bn1.weight.requires_grad
+    m.train()
+    assert not m.backbone.layer3[0].bn1.training and m.neck_3d.down_layer_0[0].norm1.training
+    assert abs(float(m.bbox_head.cls_conv.bias[0]) + 4.59512) < 1e-4
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference configs only exist in the build container")
+def test_reference_configs_load_unmodified_and_build():
+    from nerfdet_amd.config import Config
+    from nerfdet_amd.presets import nerfdet_cfg
+    from nerfdet_amd.registry import build_detector
+    files = sorted(glob.glob(os.path.join(REF_CFG, "*.py")))
+    assert len(files) == 5
+    for f in files:
+        cfg = Config.fromfile(f)
+        assert cfg.model.type == "nerfdet" and cfg.test_cfg.nms_pre == 1000 and cfg.data.samples_per_gpu == 1
+        assert "denorm_images" in cfg.test_collect_keys
+    cfg = Config.fromfile(os.path.join(REF_CFG, "nerfdet_res50_2x_low_res.py"))
+    ours = nerfdet_cfg(50)
+    for k, v in ours["model"].items():
+        if k != "pretrained":
+            got = cfg.model[k]
+            assert (tuple(got) if isinstance(got, (list, tuple)) else got) == (tuple(v) if isinstance(v, (list, tuple)) else v), k
+    cfg.model.pretrained = None  # torchvision:// is a network fetch
+    det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    assert det.N_samples == 64 and det.N_rand == 2048 and det.bbox_head.test_cfg.score_thr == 0.01
+    cfg101 = Config.fromfile(os.path.join(REF_CFG, "nerfdet_res101_2x_low_res_depth_sp.py"))
+    assert cfg101.model.backbone.depth == 101 and cfg101.model.depth_supervise is True
+
+
+def test_losses_and_targets_cpu_math():
+    from nerfdet_amd.losses import AxisAlignedIoULoss, CrossEntropyLoss, FocalLoss, aligned_iou_3d
+    a = torch.tensor([[0.0, 0, 0, 2, 2, 2], [0, 0, 0, 1, 1, 1]])
+    b = torch.tensor([[1.0, 1, 1, 3, 3, 3], [2, 2, 2, 3, 3, 3]])
+    iou = aligned_iou_3d(a, b)
+    assert torch.allclose(iou, torch.tensor([1.0 / 15.0, 0.0]))
+    l = AxisAlignedIoULoss()(a, b, weight=torch.tensor([1.0, 0.5]), avg_factor=1.5)
+    assert torch.allclose(l, ((1 - 1 / 15.0) * 1.0 + 1.0 * 0.5) / torch.tensor(1.5))
+    logits = torch.tensor([[2.0, -1.0], [0.5, 0.5]])
+    fl = FocalLoss()(logits, torch.tensor([0, -1]), avg_factor=1.0)  # row 2 is background (-1)
+    p = logits.sigmoid()
+    t = torch.tensor([[1.0, 0.0], [0.0, 0.0]])
+    ref = (torch.nn.functional.binary_cross_entropy_with_logits(logits, t, reduction="none")
+           * (0.25 * t + 0.75 * (1 - t)) * (t - p).abs() ** 2).sum()
+    assert torch.allclose(fl, ref)
+    ce = CrossEntropyLoss(use_sigmoid=True)(torch.tensor([0.3, -0.2]), torch.tensor([0.7, 0.1]), avg_factor=2.0)
+    assert torch.allclose(ce, torch.nn.functional.binary_cross_entropy_with_logits(torch.tensor([0.3, -0.2]), torch.tensor([0.7, 0.1]), reduction="sum") / 2)

@@ -1,7 +1,7 @@
 """GPU parity tests (through the C ABI) for the voxel-grid side of the hot path: A1-A6.
 
 Tolerances: indices / counts / validity bit-exact (outside the measure-zero set of voxel-views whose
-projected coordinate lies within 1e-3 px of a rounding boundary -- those are *reported* and must stay
+projected coordinate lies within 1e-4 px of a rounding boundary -- those are *reported* and must stay
 below 1 % of the voxels); voxel features <= 1e-4 absolute fp32 as BASELINE.json's north_star states
 (the tests use 2e-5, tighter)."""
 import numpy as np
@@ -21,7 +21,7 @@ def _ops():
     return ops
 
 
-def near_boundary_voxels(points, proj, w, h, tol=1e-3):
+def near_boundary_voxels(points, proj, w, h, tol=1e-4):
     """voxels with at least one view whose pixel coordinate is within `tol` of a .5 rounding boundary
     (or whose depth is ~0): the only places where a 1-ulp difference in the projection may flip an index."""
     u, v, d = O.project_voxels(points, proj)
@@ -169,7 +169,7 @@ def test_cfg2_full_size_vs_oracle_and_properties(device):
     assert 0.2 < frac < 0.45, frac
     bad = (gcnt.cpu() != cnt).reshape(-1)
     assert not (bad & ~excl).any(), "view count differs away from rounding boundaries"
-    assert excl.float().mean() < 0.05
+    assert excl.float().mean() < 0.01
     ok = ~(bad | excl)
     diff = (got.cpu() - mean).reshape(c, -1)[:, ok].abs().max().item()
     assert diff <= ATOL, diff
