@@ -12,6 +12,7 @@ from typing import List
 import torch
 from torch import nn
 
+from . import losses  # noqa: F401  (registers the loss types the head builds)
 from . import ops
 from .nms import aligned_3d_nms
 from .registry import HEADS, build_loss

@@ -35,7 +35,7 @@ def golden_meta(g):
 
 
 def sub_state(g, prefix):
-    return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
+    return {k[len(prefix):]: torch.as_tensor(v) for k, v in g.items() if k.startswith(prefix)}
 
 
 @pytest.fixture(scope="session")

@@ -41,24 +41,6 @@ def conv2d_probe():
             fl = 2 * 50 * 4800 * 256 * 256 * 9
             print(f"conv2d 256->256 3x3 @50x60x80 {dtype} channels_last={cl}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s", flush=True)
 
-def cpu_threads_probe():
-    from oracle import nerfdet_oracle as O
-    import bench
-    w = bench.WORKLOADS["cfg2"]
-    meta, feats, rgb = bench.synth_scene(w, 0, "cpu")
-    mapping = torch.nn.Linear(256, 32); from nerfdet_amd.nerf_mlp import VanillaNeRFRadianceField
-    mlp = VanillaNeRFRadianceField(4, 256, 3, 70, 1, 128)
-    print("cpu_count", os.cpu_count(), flush=True)
-    for th in (8, 16, 32, 64):
-        torch.set_num_threads(th)
-        ts = []
-        with torch.no_grad():
-            for i in range(2):
-                t0 = time.perf_counter()
-                O.extract_volume(feats, rgb, meta, w["n_voxels"], w["voxel_size"], mapping.weight, mapping.bias, mlp.state_dict())
-                ts.append(time.perf_counter() - t0)
-        print(f"oracle extract_volume cfg2 threads={th}: {ts}", flush=True)
-
 if __name__ == "__main__":
     for name in sys.argv[1:]:
         globals()[name]()
