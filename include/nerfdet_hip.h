@@ -104,6 +104,40 @@ int64_t ndet_nms_workspace_bytes(int n);
 int ndet_aligned_3d_nms(const float* boxes, const float* scores, const int64_t* classes, int n, float thresh,
                         int64_t* keep, int64_t* n_keep, void* workspace, void* stream);
 
+/* A9. Samples along rays. Replaces sample_along_camera_ray(), mmdet3d/models/model_utils/render_ray.py:145-189
+ * (inv_uniform=False).  ray_o, ray_d (R,3); t_rand NULL (det=True) or (R,S) uniforms in [0,1) -- the stream the
+ * reference draws with torch.rand_like, injectable for parity.  Outputs pts (R,S,3), z_vals (R,S). */
+int ndet_sample_along_rays(const float* ray_o, const float* ray_d, int R, int S, float near, float far,
+                           const float* t_rand, float* pts, float* z_vals, void* stream);
+
+/* A7+A8 fused. Replaces Projector.compute() (model_utils/projection.py:91-151, grid_sample=True) followed by
+ * compute_mask_points() (render_ray.py:71-93) and the concat / pixel mask of render_ray.py:301-303, without
+ * materialising the (R,S,n_views,3+d) tensor.
+ * pts (P,3) sample points; KE (n_views,3,4) = rows 0..2 of K(4x4) @ E(4x4) per view (render_ray.py:48-69 cameras);
+ * img_h,img_w: cameras[:, :2]; rgb: source images, element (v,c,y,x) at v*rsv + c*rsc + y*rsy + x, H x W;
+ * feat_nhwc: mapped features, element (v,y,x,c) at v*fview_pitch + y*frow_pitch + x*d + c, hf x wf, d <= 61.
+ * global_feat (P, 2*(3+d)) = [mean(3+d) | exp(-var)(3+d)]; pixel_mask (P) uint8 = (views seeing the point > 1);
+ * view_count (P) int32 or NULL. */
+int ndet_ray_view_stats(const float* pts, int n_points, const float* KE, int n_views, float img_h, float img_w,
+                        const float* rgb, int H, int W, int64_t rsv, int64_t rsc, int64_t rsy,
+                        const float* feat_nhwc, int d, int hf, int wf, int64_t fview_pitch, int64_t frow_pitch,
+                        float* global_feat, uint8_t* pixel_mask, int* view_count, void* stream);
+
+/* A7 exact API form. Replaces Projector.compute(), projection.py:91-151: rgb_feat (P, n_views, 3+d) and
+ * mask (P, n_views) fp32 0/1, materialised like the reference. Same inputs as ndet_ray_view_stats. */
+int ndet_project_sample(const float* pts, int n_points, const float* KE, int n_views, float img_h, float img_w,
+                        const float* rgb, int H, int W, int64_t rsv, int64_t rsc, int64_t rsy,
+                        const float* feat_nhwc, int d, int hf, int wf, int64_t fview_pitch, int64_t frow_pitch,
+                        float* rgb_feat, float* mask, void* stream);
+
+/* A11. Alpha compositing. Replaces raw2outputs(), render_ray.py:196-247.
+ * raw (R,S,4) = [rgb, sigma]; z_vals (R,S); pixel_mask (R,S) uint8 or NULL; zminmax: DEVICE pointer to
+ * {z_vals.min(), z_vals.max()} (the depth clamp is global, render_ray.py:236).
+ * Outputs rgb_map (R,3), depth_map (R), weights/alpha/transparency (R,S), ray_mask (R) uint8 (NULL if no pixel_mask). */
+int ndet_composite(const float* raw, const float* z_vals, const uint8_t* pixel_mask, int R, int S, int white_bkgd,
+                   const float* zminmax, float* rgb_map, float* depth_map, float* weights, uint8_t* ray_mask,
+                   float* alpha, float* transparency, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

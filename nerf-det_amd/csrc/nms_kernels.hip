@@ -105,8 +105,11 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long* __re
         for (int k = 0; k < PF; ++k) {
             const int i = i0 + k;
             if (i < n) {
-                const unsigned long long wsel = __shfl(removed, i >> 6);
-                const bool gone = (wsel >> (i & 63)) & 1ull;
+                // word i/64 of the removed-set lives in lane i/64: a scalar v_readlane, not a cross-lane shuffle,
+                // keeps the serial dependence (removed -> gone -> removed) short
+                const unsigned half = (i & 32) ? (unsigned)(removed >> 32) : (unsigned)removed;
+                const unsigned wsel = (unsigned)__builtin_amdgcn_readlane((int)half, i >> 6);
+                const bool gone = (wsel >> (i & 31)) & 1u;
                 if (!gone) {
                     if (lane == 0) keep[kept] = (int64_t)order[i];
                     ++kept;

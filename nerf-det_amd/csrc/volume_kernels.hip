@@ -22,7 +22,12 @@ extern "C" int ndet_version(void) { return 100; }
 extern "C" const char* ndet_last_error(void) { return g_err; }
 
 #define VOX_PER_TILE 16  // one workgroup = 4 waves x 4 voxels = 16 consecutive voxels (one z column at Z=16)
-#define GATHER_BATCH 4   // independent 1-KiB row loads a wave keeps in flight per voxel
+#ifndef GATHER_BATCH
+#define GATHER_BATCH 8  // independent 1-KiB row loads a wave keeps in flight per voxel
+#endif
+#ifndef K1_MIN_WAVES
+#define K1_MIN_WAVES 1  // __launch_bounds__ 2nd argument (waves per SIMD) for K1; tuned with tools/tune_k1.py
+#endif
 
 // ------------------------------------------------------------------------------------------
 // A2  get_points  (nerfdet.py:380-390)
@@ -148,11 +153,12 @@ extern "C" int ndet_backproject(const float* features, int n_views, int C, int h
 // writes = (C + 2) * N * 4 bytes.
 // ------------------------------------------------------------------------------------------
 template <int NCHUNK, bool GATE, int LAYOUT>
-__global__ __launch_bounds__(256) void k_backproject_aggregate(
+__global__ __launch_bounds__(256, K1_MIN_WAVES) void k_backproject_aggregate(
     const float* __restrict__ feat, int n_views, int C, int h, int w, int64_t view_pitch, int row_pitch,
     const float* __restrict__ points, int N, const float* __restrict__ proj, const float* __restrict__ alpha,
     float* __restrict__ out, int64_t* __restrict__ count, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // LAYOUT_CN only: [16][C + 4]
+    constexpr int VPW = VOX_PER_TILE / 4;  // voxels per wave, processed together
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int tile = ndet_xcd_remap(blockIdx.x, n_tiles);
@@ -160,25 +166,54 @@ __global__ __launch_bounds__(256) void k_backproject_aggregate(
     const int c4 = C >> 2;
     const int ldp = C + 4;
 
-    for (int j = 0; j < VOX_PER_TILE / 4; ++j) {
-        const int slot = j * 4 + wave;  // the 4 waves work on 4 neighbouring voxels at a time
-        const int n = n0 + slot;
-        if (n >= N) continue;  // wave-uniform
-        const float px = points[n], py = points[N + n], pz = points[2 * N + n];
-        float4 acc[NCHUNK];
+    // the wave's voxels: slots wave, wave+4, wave+8, wave+12 of the tile (the 4 waves of the workgroup work on
+    // 4 neighbouring voxels at a time); coordinates of all of them are fetched up front
+    float px[VPW], py[VPW], pz[VPW];
+    bool live[VPW];
 #pragma unroll
-        for (int q = 0; q < NCHUNK; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        int cnt = 0;
+    for (int j = 0; j < VPW; ++j) {
+        const int n = n0 + j * 4 + wave;
+        live[j] = n < N;  // wave-uniform
+        const int nn = live[j] ? n : 0;
+        px[j] = points[nn];
+        py[j] = points[N + nn];
+        pz[j] = points[2 * N + nn];
+    }
+    float4 acc[VPW][NCHUNK];
+    int cnt[VPW];
+#pragma unroll
+    for (int j = 0; j < VPW; ++j) {
+        cnt[j] = 0;
+#pragma unroll
+        for (int q = 0; q < NCHUNK; ++q) acc[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
-        for (int r0 = 0; r0 < n_views; r0 += 64) {
-            const int v = r0 + lane;
+    for (int r0 = 0; r0 < n_views; r0 += 64) {
+        // phase A: lanes over views, one camera matrix per lane, all voxels of the wave projected back to back
+        const int v = r0 + lane;
+        float P[12];
+        {
+            const float4* pm = reinterpret_cast<const float4*>(proj + (v < n_views ? v : 0) * 12);
+            const float4 a = pm[0], b = pm[1], c = pm[2];
+            P[0] = a.x; P[1] = a.y; P[2] = a.z; P[3] = a.w;
+            P[4] = b.x; P[5] = b.y; P[6] = b.z; P[7] = b.w;
+            P[8] = c.x; P[9] = c.y; P[10] = c.z; P[11] = c.w;
+        }
+        int off[VPW];
+        unsigned long long mask[VPW];
+#pragma unroll
+        for (int j = 0; j < VPW; ++j) {
             int xi = 0, yi = 0;
-            bool ok = false;
-            if (v < n_views) ok = ndet_project(proj + v * 12, px, py, pz, w, h, xi, yi);
-            const int off = yi * row_pitch + xi * C;  // floats inside one view (< 2^31, checked on the host)
-            unsigned long long m = __ballot(ok);
-            cnt += __popcll(m);
-            const float* vbase = feat + (int64_t)r0 * view_pitch;
+            const bool ok = (v < n_views) && live[j] && ndet_project(P, px[j], py[j], pz[j], w, h, xi, yi);
+            off[j] = yi * row_pitch + xi * C;  // floats inside one view (< 2^31, checked on the host)
+            mask[j] = __ballot(ok);
+            cnt[j] += __popcll(mask[j]);
+        }
+        // phase B: walk the set bits; GATHER_BATCH independent row loads in flight
+        const float* vbase = feat + (int64_t)r0 * view_pitch;
+#pragma unroll
+        for (int j = 0; j < VPW; ++j) {
+            unsigned long long m = mask[j];
             int b = 0;
             while (m) {
                 float4 t[GATHER_BATCH][NCHUNK];
@@ -190,7 +225,7 @@ __global__ __launch_bounds__(256) void k_backproject_aggregate(
                         b = __builtin_ctzll(m);
                         m &= (m - 1ull);
                     }  // else: re-read the previous row (L1 hit), discarded below
-                    const int o = __builtin_amdgcn_readlane(off, b);
+                    const int o = __builtin_amdgcn_readlane(off[j], b);
                     const float4* p = reinterpret_cast<const float4*>(vbase + (int64_t)b * view_pitch + o);
 #pragma unroll
                     for (int q = 0; q < NCHUNK; ++q) {
@@ -202,31 +237,37 @@ __global__ __launch_bounds__(256) void k_backproject_aggregate(
                 for (int k = 0; k < GATHER_BATCH; ++k) {
                     if (has[k]) {
 #pragma unroll
-                        for (int q = 0; q < NCHUNK; ++q) acc[q] = ndet_add4(acc[q], t[k][q]);
+                        for (int q = 0; q < NCHUNK; ++q) acc[j][q] = ndet_add4(acc[j][q], t[k][q]);
                     }
                 }
             }
         }
+    }
 
-        // volume_sum / (valid + 1e-8); zero where no view sees the voxel (nerfdet.py:175-176);
-        // optionally alpha * mean, again zeroed at count 0 (nerfdet.py:259-261).
-        const float denom = (float)cnt + 1e-8f;
+    // volume_sum / (valid + 1e-8); zero where no view sees the voxel (nerfdet.py:175-176);
+    // optionally alpha * mean, again zeroed at count 0 (nerfdet.py:259-261).
+#pragma unroll
+    for (int j = 0; j < VPW; ++j) {
+        if (!live[j]) continue;
+        const int slot = j * 4 + wave;
+        const int n = n0 + slot;
+        const float denom = (float)cnt[j] + 1e-8f;
         float a = 1.0f;
         if (GATE) a = alpha[n];
 #pragma unroll
         for (int q = 0; q < NCHUNK; ++q) {
             float4 mean;
-            mean.x = acc[q].x / denom;
-            mean.y = acc[q].y / denom;
-            mean.z = acc[q].z / denom;
-            mean.w = acc[q].w / denom;
+            mean.x = acc[j][q].x / denom;
+            mean.y = acc[j][q].y / denom;
+            mean.z = acc[j][q].z / denom;
+            mean.w = acc[j][q].w / denom;
             if (GATE) {
                 mean.x = a * mean.x;
                 mean.y = a * mean.y;
                 mean.z = a * mean.z;
                 mean.w = a * mean.w;
             }
-            if (cnt == 0) mean = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cnt[j] == 0) mean = make_float4(0.f, 0.f, 0.f, 0.f);
             const int ci = lane + q * 64;
             if (ci < c4) {
                 if (LAYOUT == NDET_LAYOUT_NC)
@@ -235,7 +276,7 @@ __global__ __launch_bounds__(256) void k_backproject_aggregate(
                     *reinterpret_cast<float4*>(smem + slot * ldp + ci * 4) = mean;
             }
         }
-        if (lane == 0) count[n] = (int64_t)cnt;
+        if (lane == 0) count[n] = (int64_t)cnt[j];
     }
 
     if (LAYOUT == NDET_LAYOUT_CN) {

@@ -1,0 +1,237 @@
+"""Host mirror of the NeRF ray branch (A7-A12): ``Projector`` (mmdet3d/models/model_utils/projection.py:20-151),
+``compute_mask_points`` / ``sample_along_camera_ray`` / ``raw2outputs`` / ``render_rays_func`` / ``render_rays``
+(model_utils/render_ray.py:48-93,145-327,371-520), same signatures, bodies on the HIP kernels of
+csrc/ray_kernels.hip.  The fused path (:func:`ray_view_stats`) never builds the (R,S,n_views,35) tensor."""
+from __future__ import annotations
+
+from collections import OrderedDict
+from ctypes import c_void_p
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import check
+
+Tensor = torch.Tensor
+rng = np.random.RandomState(234)  # render_ray.py:20 -- module-global stream used for ray selection
+
+
+def _ptr(t):
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(t):
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+# ------------------------------------------------------------------------------------------------------
+# A1 (ray-branch twin)
+# ------------------------------------------------------------------------------------------------------
+def _compute_projection(img_meta: dict) -> Tensor:
+    """(1,n_views,34) rows ``[h, w | K(4x4) | E(4x4)]``, intrinsics rows 0-1 / (ori_h/img_h).  render_ray.py:48-69."""
+    ext = img_meta["lidar2img"]["extrinsic"]
+    n = len(ext)
+    k = torch.tensor(np.asarray(img_meta["lidar2img"]["intrinsic"], dtype=np.float32)[:4, :4])
+    k[:2] /= img_meta["ori_shape"][0] / img_meta["img_shape"][0]
+    size = torch.tensor([float(img_meta["img_shape"][0]), float(img_meta["img_shape"][1])])
+    e = torch.from_numpy(np.stack([np.asarray(x, dtype=np.float32) for x in ext])).reshape(n, 16)
+    return torch.cat([size.expand(n, 2), k.reshape(1, 16).expand(n, 16), e], dim=-1).unsqueeze(0)
+
+
+def _camera_matrices(train_cameras: Tensor) -> Tuple[Tensor, float, float]:
+    """cameras (n_views,34) -> KE (n_views,3,4) = rows 0..2 of K @ E (projection.py:52-58), h, w."""
+    cams = train_cameras.detach().to("cpu", torch.float32)
+    k = cams[:, 2:18].reshape(-1, 4, 4)
+    e = cams[:, -16:].reshape(-1, 4, 4)
+    ke = k.bmm(e)[:, :3, :].contiguous()
+    return ke, float(cams[0, 0]), float(cams[0, 1])
+
+
+def _prep_sources(train_imgs: Tensor, featmaps: Tensor):
+    """train_imgs (1,n_v,H,W,3) as the reference passes it (a permuted view of the (n_v,3,H,W) images) or the
+    (n_v,3,H,W) tensor itself; featmaps logical (n_v,d,h,w)."""
+    if train_imgs.dim() == 5:
+        assert train_imgs.shape[0] == 1, "only support batch_size=1 for now"  # projection.py:100-101
+        rgb = train_imgs.squeeze(0).permute(0, 3, 1, 2)
+    else:
+        rgb = train_imgs
+    if rgb.dtype != torch.float32:
+        rgb = rgb.float()
+    if rgb.stride(3) != 1:
+        rgb = rgb.contiguous()
+    f = ops.to_channels_last(featmaps)
+    return rgb, f
+
+
+def ray_view_stats(xyz: Tensor, train_imgs: Tensor, train_cameras: Tensor, featmaps: Tensor):
+    """Fused A7+A8: sample points (R,S,3) -> ``globalfeat`` (R,S,2*(3+d)), ``pixel_mask`` (R,S) bool,
+    ``view_count`` (R,S) int32.  Equals Projector.compute + compute_mask_points + cat + ``mask.sum(2) > 1``
+    (render_ray.py:299-303)."""
+    if not xyz.is_cuda:
+        raise RuntimeError("nerfdet_amd.rays: tensors must live on the GPU (no CPU fallback)")
+    cams = train_cameras.squeeze(0) if train_cameras.dim() == 3 else train_cameras
+    ke, h, w = _camera_matrices(cams)
+    ke = ke.to(xyz.device)
+    rgb, f = _prep_sources(train_imgs, featmaps)
+    n_v, d, hf, wf = f.shape
+    assert rgb.shape[0] == n_v and ke.shape[0] == n_v
+    shape = xyz.shape[:-1]
+    pts = xyz.to(torch.float32).reshape(-1, 3).contiguous()
+    n = pts.shape[0]
+    glob = torch.empty((n, 2 * (3 + d)), dtype=torch.float32, device=xyz.device)
+    pm = torch.empty((n,), dtype=torch.bool, device=xyz.device)
+    vc = torch.empty((n,), dtype=torch.int32, device=xyz.device)
+    check(_lib.load().ndet_ray_view_stats(_ptr(pts), n, _ptr(ke), n_v, h, w, _ptr(rgb), rgb.shape[2], rgb.shape[3],
+                                          rgb.stride(0), rgb.stride(1), rgb.stride(2), _ptr(f), d, hf, wf, f.stride(0), f.stride(2),
+                                          _ptr(glob), _ptr(pm), _ptr(vc), _stream(xyz)), "ray_view_stats")
+    return glob.view(*shape, -1), pm.view(*shape), vc.view(*shape)
+
+
+class Projector:
+    """projection.py:20-151.  ``compute`` keeps the reference's signature and materialised outputs."""
+
+    def __init__(self, device="cuda"):
+        self.device = device
+
+    def compute(self, xyz, train_imgs, train_cameras, featmaps=None, grid_sample=True):
+        assert (train_imgs.shape[0] == 1) and (train_cameras.shape[0] == 1)  # projection.py:100-101
+        assert grid_sample, "grid_sample=False indexes (y, y) in the reference (projection.py:142) and is dead code"
+        assert featmaps is not None, "featmaps=None is only reached in nerf_mode='volume' (dead in the configs)"
+        if not xyz.is_cuda:
+            raise RuntimeError("nerfdet_amd.rays: tensors must live on the GPU (no CPU fallback)")
+        ke, h, w = _camera_matrices(train_cameras.squeeze(0))
+        ke = ke.to(xyz.device)
+        rgb, f = _prep_sources(train_imgs, featmaps)
+        n_v, d, hf, wf = f.shape
+        r, s = xyz.shape[:2]
+        pts = xyz.to(torch.float32).reshape(-1, 3).contiguous()
+        out = torch.empty((r, s, n_v, 3 + d), dtype=torch.float32, device=xyz.device)
+        mask = torch.empty((r, s, n_v, 1), dtype=torch.float32, device=xyz.device)
+        check(_lib.load().ndet_project_sample(_ptr(pts), r * s, _ptr(ke), n_v, h, w, _ptr(rgb), rgb.shape[2], rgb.shape[3],
+                                              rgb.stride(0), rgb.stride(1), rgb.stride(2), _ptr(f), d, hf, wf, f.stride(0),
+                                              f.stride(2), _ptr(out), _ptr(mask), _stream(xyz)), "Projector.compute")
+        return out, mask
+
+
+def compute_mask_points(feature: Tensor, mask: Tensor) -> Tuple[Tensor, Tensor]:
+    """render_ray.py:71-93 on already-materialised samples (API parity; the fused path is ray_view_stats).
+    Plain tensor algebra on the GPU."""
+    denom = torch.sum(mask, dim=2, keepdim=True) + 1e-8
+    mean = torch.sum(feature * (mask / denom), dim=2, keepdim=True)
+    var = torch.sum((feature - mean) ** 2, dim=2, keepdim=True) / denom
+    return mean, torch.exp(-var)
+
+
+# ------------------------------------------------------------------------------------------------------
+# A9
+# ------------------------------------------------------------------------------------------------------
+def sample_along_camera_ray(ray_o, ray_d, depth_range, N_samples, inv_uniform=False, det=False, t_rand: Optional[Tensor] = None):
+    """render_ray.py:145-189.  ``t_rand`` (R,S) replaces the reference's ``torch.rand_like`` draw when given."""
+    assert not inv_uniform, "inv_uniform sampling is never enabled by the nerfdet configs"
+    near, far = float(depth_range[0]), float(depth_range[1])
+    assert near > 0 and far > 0 and far > near  # render_ray.py:161
+    if not ray_d.is_cuda:
+        raise RuntimeError("nerfdet_amd.rays: tensors must live on the GPU (no CPU fallback)")
+    o = ray_o.to(torch.float32).contiguous()
+    d = ray_d.to(torch.float32).contiguous()
+    r = d.shape[0]
+    if not det and t_rand is None:
+        t_rand = torch.rand((r, N_samples), dtype=torch.float32, device=d.device)
+    if det:
+        t_rand = None
+    elif t_rand is not None:
+        t_rand = t_rand.to(torch.float32).contiguous()
+    pts = torch.empty((r, N_samples, 3), dtype=torch.float32, device=d.device)
+    z = torch.empty((r, N_samples), dtype=torch.float32, device=d.device)
+    check(_lib.load().ndet_sample_along_rays(_ptr(o), _ptr(d), r, N_samples, near, far, _ptr(t_rand), _ptr(pts), _ptr(z), _stream(d)),
+          "sample_along_camera_ray")
+    return pts, z
+
+
+# ------------------------------------------------------------------------------------------------------
+# A11
+# ------------------------------------------------------------------------------------------------------
+def raw2outputs(raw, z_vals, mask, white_bkgd=False):
+    """render_ray.py:196-247 -> OrderedDict(rgb, depth, weights, mask, alpha, z_vals, transparency)."""
+    if not raw.is_cuda:
+        raise RuntimeError("nerfdet_amd.rays: tensors must live on the GPU (no CPU fallback)")
+    r, s = raw.shape[:2]
+    raw_c = raw.to(torch.float32).contiguous()
+    z = z_vals.to(torch.float32).contiguous()
+    dev = raw.device
+    zmm = torch.stack([z.min(), z.max()])
+    pm = None if mask is None else mask.to(torch.bool).contiguous()
+    rgb = torch.empty((r, 3), dtype=torch.float32, device=dev)
+    depth = torch.empty((r,), dtype=torch.float32, device=dev)
+    wts = torch.empty((r, s), dtype=torch.float32, device=dev)
+    alpha = torch.empty((r, s), dtype=torch.float32, device=dev)
+    trans = torch.empty((r, s), dtype=torch.float32, device=dev)
+    rmask = None if mask is None else torch.empty((r,), dtype=torch.bool, device=dev)
+    check(_lib.load().ndet_composite(_ptr(raw_c), _ptr(z), _ptr(pm), r, s, int(bool(white_bkgd)), _ptr(zmm), _ptr(rgb), _ptr(depth),
+                                     _ptr(wts), _ptr(rmask), _ptr(alpha), _ptr(trans), _stream(raw)), "raw2outputs")
+    return OrderedDict([("rgb", rgb), ("depth", depth), ("weights", wts), ("mask", rmask), ("alpha", alpha),
+                        ("z_vals", z_vals), ("transparency", trans)])
+
+
+# ------------------------------------------------------------------------------------------------------
+# A12
+# ------------------------------------------------------------------------------------------------------
+def render_rays_func(ray_o, ray_d, mean_volume, cov_volume, features_2D, img, aabb, near_far_range, N_samples, N_rand=4096,
+                     nerf_mlp=None, img_meta=None, projector=None, mode="volume", nerf_sample_view=3, inv_uniform=False,
+                     N_importance=0, det=False, is_train=True, white_bkgd=False, gt_rgb=None, gt_depth=None, t_rand=None):
+    """render_ray.py:250-369, ``mode='image'``, ``N_importance=0`` (the only reachable branch)."""
+    assert mode == "image", "nerf_mode='volume' is not used by any nerfdet config"
+    assert N_importance == 0, "the N_importance>0 branch references undefined names in the reference (render_ray.py:329-367)"
+    ret = {"outputs_coarse": None, "outputs_fine": None, "gt_rgb": gt_rgb, "gt_depth": gt_depth}
+    pts, z_vals = sample_along_camera_ray(ray_o, ray_d, near_far_range, N_samples, inv_uniform=inv_uniform, det=det, t_rand=t_rand)
+    cams = _compute_projection(img_meta)
+    globalfeat, pixel_mask, _ = ray_view_stats(pts, img, cams, features_2D)
+    rgb_pts, density_pts = nerf_mlp(pts, ray_d, globalfeat)
+    ret["sigma"] = density_pts
+    ret["outputs_coarse"] = raw2outputs(torch.cat([rgb_pts, density_pts], dim=-1), z_vals, pixel_mask, white_bkgd=white_bkgd)
+    return ret
+
+
+def render_rays(ray_batch, mean_volume, cov_volume, features_2D, img, aabb, near_far_range, N_samples, N_rand=4096, nerf_mlp=None,
+                img_meta=None, projector=None, mode="volume", nerf_sample_view=3, inv_uniform=False, N_importance=0, det=False,
+                is_train=True, white_bkgd=False, render_testing=False):
+    """render_ray.py:371-520: training = drop rays without depth, draw ``N_rand`` rays from the module-global
+    RandomState, one ``render_rays_func``; ``render_testing`` = every ray of the target views in chunks of
+    ``N_rand``, deterministic sampling; otherwise ``None``."""
+    ray_o, ray_d, gt_rgb, gt_depth = ray_batch["ray_o"], ray_batch["ray_d"], ray_batch["gt_rgb"], ray_batch["gt_depth"]
+    if is_train:
+        ray_o, ray_d, gt_rgb = ray_o.view(-1, 3), ray_d.view(-1, 3), gt_rgb.view(-1, 3)
+        if len(gt_depth) != 0:
+            gt_depth = gt_depth.view(-1, 1)
+            keep = (gt_depth > 0).squeeze(-1)
+            ray_o, ray_d, gt_rgb, gt_depth = ray_o[keep], ray_d[keep], gt_rgb[keep], gt_depth[keep]
+        else:
+            gt_depth = None
+        sel = torch.from_numpy(rng.choice(ray_d.shape[0], size=(N_rand,), replace=False)).to(ray_d.device)
+        ray_o, ray_d, gt_rgb = ray_o[sel], ray_d[sel], gt_rgb[sel]
+        if gt_depth is not None:
+            gt_depth = gt_depth[sel]
+        return render_rays_func(ray_o, ray_d, mean_volume, cov_volume, features_2D, img, aabb, near_far_range, N_samples, N_rand,
+                                nerf_mlp, img_meta, projector, mode, nerf_sample_view, inv_uniform, N_importance, det, is_train,
+                                white_bkgd, gt_rgb, gt_depth)
+    if render_testing:
+        nerf_size = ray_batch["nerf_sizes"][0]
+        view_num = ray_o.shape[1]
+        hh, ww = int(nerf_size[0][0]), int(nerf_size[0][1])
+        ray_o, ray_d, gt_rgb = ray_o.view(-1, 3), ray_d.view(-1, 3), gt_rgb.view(-1, 3)
+        gt_depth = gt_depth.view(-1, 1) if len(gt_depth) != 0 else None
+        assert view_num * hh * ww == ray_o.shape[0]  # render_ray.py:468
+        rgbs, depths = [], []
+        for i in range(0, ray_o.shape[0], N_rand):
+            ret = render_rays_func(ray_o[i:i + N_rand], ray_d[i:i + N_rand], mean_volume, cov_volume, features_2D, img, aabb,
+                                   near_far_range, N_samples, N_rand, nerf_mlp, img_meta, projector, mode, nerf_sample_view,
+                                   inv_uniform, N_importance, True, is_train, white_bkgd, gt_rgb, gt_depth)
+            rgbs.append(ret["outputs_coarse"]["rgb"])
+            depths.append(ret["outputs_coarse"]["depth"])
+        return {"outputs_coarse": {"rgb": torch.cat(rgbs, dim=0).view(view_num, hh, ww, 3),
+                                   "depth": torch.cat(depths, dim=0).view(view_num, hh, ww, 1)},
+                "gt_rgb": gt_rgb.view(view_num, hh, ww, 3),
+                "gt_depth": gt_depth.view(view_num, hh, ww, 1) if gt_depth is not None else None}
+    return None
