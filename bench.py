@@ -172,7 +172,7 @@ def main():
             x, b, stride = det_gpu.extract_2d(batch["img"])
             e1 = ev()
             out = V.extract_volume(x, rb["denorm_images"][0], batch["img_metas"][0], det_gpu.n_voxels, det_gpu.voxel_size,
-                                   det_gpu.mapping, det_gpu.nerf_mlp, stride=stride, channels_last_out=False)
+                                   det_gpu.mapping, det_gpu.nerf_mlp, stride=stride, channels_last_out=True)
             e2 = ev()
             x3 = det_gpu.neck_3d(out["volume"].unsqueeze(0))
             e3 = ev()

@@ -138,6 +138,20 @@ int ndet_composite(const float* raw, const float* z_vals, const uint8_t* pixel_m
                    const float* zminmax, float* rgb_map, float* depth_map, float* weights, uint8_t* ray_mask,
                    float* alpha, float* transparency, void* stream);
 
+/* A13/A14. 3D convolution, channels-last, fp32 on the matrix cores, fused epilogue.  Replaces nn.Conv3d /
+ * nn.ConvTranspose3d(2,2) + BatchNorm3d(eval) + ReLU (+ residual add) of mmdet3d/models/necks/imvoxelnet.py:8-67,
+ * 233-260 and the head convs of mmdet3d/models/dense_heads/imvoxel_head_v2.py:45-49,442-449.
+ * in (D,H,W,Cin) fp32, Cin % 32 == 0; w_packed (taps, Cout, Cin) with tap = (kd*k + kh)*k + kw
+ * [transposed: (8, Cout, Cin), tap = kd*4 + kh*2 + kw, out voxel = 2*in + (kd,kh,kw)];
+ * out (OD,OH,OW,Cout), O = (I + 2*(k/2) - k)/stride + 1 [transposed: 2*I].  ksize 3 or 1, stride 1 or 2.
+ * Epilogue: v = acc*scale[co] + shift[co] (if scale != NULL); relu == 2: max(v,0); v += residual (if != NULL);
+ * relu == 1: max(v,0).  splits > 1: split-K over blockIdx.z into `workspace` (ndet_conv3d_workspace_bytes) and a
+ * fixed-order reduction (bitwise reproducible).  tile: 0 auto, 64 or 128. */
+int64_t ndet_conv3d_workspace_bytes(int D, int H, int W, int Cin, int Cout, int ksize, int stride, int splits);
+int ndet_conv3d_ndhwc(const float* in, const float* w_packed, float* out, int D, int H, int W, int Cin, int Cout,
+                      int ksize, int stride, int transposed, const float* scale, const float* shift,
+                      const float* residual, int relu, int splits, int tile, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,110 @@
+"""Host side of the MFMA 3D convolution (csrc/conv3d_kernels.hip): weight / BatchNorm packing and the launcher.
+
+Layout: activations channels-last ``(D,H,W,C)`` fp32; weights packed ``(taps, Cout, Cin)``.  Eval-mode BatchNorm3d is
+folded into the epilogue as ``alpha = gamma/sqrt(var+eps)``, ``beta = bias - mean*alpha`` (the form ATen's CPU batch-norm
+uses), followed by optional residual add and ReLU -- replacing nn.Conv3d/ConvTranspose3d + BatchNorm3d + ReLU of
+mmdet3d/models/necks/imvoxelnet.py:36-67,233-260."""
+from __future__ import annotations
+
+from ctypes import c_void_p
+from typing import Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import check
+
+_cache = {}
+
+
+def _ptr(t):
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+def pack_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+    """Conv3d weight (Cout,Cin,k,k,k) -> (k^3, Cout, Cin); ConvTranspose3d weight (Cin,Cout,2,2,2) -> (8, Cout, Cin)."""
+    if transposed:
+        cin, cout = w.shape[:2]
+        return w.permute(2, 3, 4, 1, 0).reshape(-1, cout, cin).contiguous().float()
+    cout, cin = w.shape[:2]
+    return w.permute(2, 3, 4, 0, 1).reshape(-1, cout, cin).contiguous().float()
+
+
+def fold_bn(bn: Optional[nn.BatchNorm3d], bias: Optional[torch.Tensor], cout: int, device):
+    """(scale, shift) of the fused epilogue, or (None, None) when there is nothing to apply."""
+    if bn is None and bias is None:
+        return None, None
+    if bn is None:
+        return torch.ones(cout, device=device), bias.detach().float().contiguous()
+    alpha = bn.weight.detach().float() * (1.0 / torch.sqrt(bn.running_var.float() + bn.eps))
+    beta = bn.bias.detach().float() - bn.running_mean.float() * alpha
+    if bias is not None:
+        beta = beta + bias.detach().float() * alpha
+    return alpha.contiguous(), beta.contiguous()
+
+
+def packed(convs: Sequence[nn.Module], bn: Optional[nn.BatchNorm3d] = None):
+    """Pack (and cache) one conv, or several convs sharing an input concatenated along Cout.  The cache entry is
+    rebuilt when any parameter was updated in place (optimizer step, load_state_dict)."""
+    tensors = [t for c in convs for t in (c.weight, c.bias) if t is not None]
+    if bn is not None:
+        tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    key = tuple(id(c) for c in convs) + (id(bn),)
+    stamp = tuple((t.data_ptr(), t._version) for t in tensors)
+    hit = _cache.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    tr = isinstance(convs[0], nn.ConvTranspose3d)
+    w = torch.cat([pack_weight(c.weight.detach(), tr) for c in convs], dim=1).contiguous()
+    cout = w.shape[1]
+    bias = None
+    if any(c.bias is not None for c in convs):
+        bias = torch.cat([c.bias.detach() if c.bias is not None else torch.zeros(c.weight.shape[1 if tr else 0], device=w.device)
+                          for c in convs])
+    scale, shift = fold_bn(bn, bias, cout, w.device)
+    val = dict(w=w, scale=scale, shift=shift, cout=cout, cin=w.shape[2], ksize=convs[0].kernel_size[0], stride=convs[0].stride[0],
+               transposed=tr)
+    _cache[key] = (stamp, val)
+    return val
+
+
+def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = None, relu: int = 0, splits: int = 0, tile: int = 0):
+    """x (D,H,W,Cin) contiguous fp32 on the GPU -> (OD,OH,OW,Cout).  relu: 0 none, 1 after the residual add, 2 before it."""
+    if not x.is_cuda:
+        raise RuntimeError("nerfdet_amd.conv3d: tensors must live on the GPU (no CPU fallback)")
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+    d, h, w, cin = x.shape
+    assert cin == pk["cin"], (cin, pk["cin"])
+    k, s, tr, cout = pk["ksize"], pk["stride"], pk["transposed"], pk["cout"]
+    if tr:
+        od, oh, ow = 2 * d, 2 * h, 2 * w
+    else:
+        pad = k // 2
+        od, oh, ow = ((v + 2 * pad - k) // s + 1 for v in (d, h, w))
+    out = torch.empty((od, oh, ow, cout), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous()
+    lib = _lib.load()
+    m = d * h * w if tr else od * oh * ow
+    if splits == 0:  # fill the 256 CUs: split K when the output tile grid alone cannot
+        splits = 1
+        if not tr:
+            t = tile or (128 if ((m + 127) // 128) * ((cout + 127) // 128) >= 192 and cout >= 128 else 64)
+            tiles = ((m + t - 1) // t) * ((cout + t - 1) // t)
+            iters = k ** 3 * (cin // 32)
+            if tiles < 256:
+                splits = max(1, min(8, (384 + tiles - 1) // tiles, iters // 8))
+    ws = None
+    if splits > 1:
+        ws = torch.empty((int(lib.ndet_conv3d_workspace_bytes(d, h, w, cin, cout, k, s, splits)),), dtype=torch.uint8, device=x.device)
+    st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    check(lib.ndet_conv3d_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), d, h, w, cin, cout, k, s, int(tr), _ptr(pk["scale"]), _ptr(pk["shift"]),
+                                _ptr(residual), relu, splits, tile, _ptr(ws), st), "conv3d_ndhwc")
+    return out
+
+
+def to_ndhwc(x: torch.Tensor) -> torch.Tensor:
+    """logical (C,X,Y,Z) -> contiguous (X,Y,Z,C) (free when the memory already is channels-last)."""
+    y = x.permute(1, 2, 3, 0)
+    return y if y.is_contiguous() else y.contiguous()

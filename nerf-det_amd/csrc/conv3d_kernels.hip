@@ -1,0 +1,280 @@
+// A13/A14: 3D convolutions of the voxel neck and head as a direct implicit GEMM on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains, no reduced precision), channels-last (NDHWC).
+//
+//   out[m, co] = epilogue( sum_{tap} sum_{ci} in[nbr(m, tap), ci] * Wp[tap][co][ci] )
+//
+// GEMM view: M = output voxels, N = Cout, K = taps * Cin.  One workgroup = 256 threads = 2 x 2 waves computes a
+// BM x BN tile; K is walked tap-major in steps of BK = 32 input channels.  A rows are gathered on the fly (one
+// 128-byte channel run of the neighbour voxel per (row, tap), zeros outside the grid) -- nothing like the 27x
+// im2col buffer the vendor path materialises.  Both operand tiles sit K-contiguous in LDS ([rows][BK + 4]); a lane
+// reads 4 consecutive k with one ds_read_b128 and feeds them to 4 successive MFMAs (the k permutation is the same
+// for A and B, so the product is unchanged).  Global -> register -> LDS staging is double buffered: the loads of
+// K-step i+1 are in flight while step i is multiplied; one barrier per step.
+// Epilogue (fused): per-channel scale/shift (eval-mode BatchNorm as alpha = gamma/sqrt(var+eps), beta = bias -
+// mean*alpha, the form ATen's CPU kernel uses), residual add, ReLU.  Split-K variants write raw partial sums to a
+// workspace and a small second kernel reduces them in a fixed order (bitwise reproducible) and applies the epilogue.
+//
+// Replaces nn.Conv3d / nn.ConvTranspose3d(k=2,s=2) + BatchNorm3d(eval) + ReLU of
+// mmdet3d/models/necks/imvoxelnet.py:8-67,233-260 and the head convs of dense_heads/imvoxel_head_v2.py:45-49.
+#include "ndet_common.hpp"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CBK 32          // K step (input channels per step)
+#define CLD (CBK + 4)   // LDS row stride in floats (144 B: 16-B aligned, spreads ds_read_b128 over the banks)
+
+struct Conv3dParams {
+    const float* in;      // (D, H, W, Cin)
+    const float* w;       // packed (taps, Cout, Cin)
+    float* out;           // (OD, OH, OW, Cout)   [transposed: (2D, 2H, 2W, Cout)]
+    const float* scale;   // (Cout) or null
+    const float* shift;   // (Cout) or null
+    const float* res;     // same shape as out, or null
+    float* partial;       // split-K workspace (splits, M, Cout) or null
+    int D, H, W, Cin;
+    int OD, OH, OW, Cout;
+    int ksize, stride, pad;
+    int relu;             // 0 none, 1 ReLU last (after the residual add), 2 ReLU before the residual add
+    int transposed;       // 1: ConvTranspose3d k=2 s=2 (blockIdx.z = tap)
+    int splits;           // split-K factor (blockIdx.z = split) when !transposed
+    int M;                // GEMM rows: output voxels (input voxels when transposed)
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_conv3d_igemm(const Conv3dParams p) {
+    constexpr int WM = BM / 2, WN = BN / 2;     // per-wave tile
+    constexpr int MT = WM / 16, NT = WN / 16;   // 16x16 MFMA tiles per wave
+    constexpr int AR = BM / 32, BR = BN / 32;   // rows each thread stages per operand
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As = lds;                       // [2][BM][CLD]
+    float* Bs = lds + 2 * BM * CLD;        // [2][BN][CLD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int chunk = tid & 7;      // which 4-float piece of the 32-float K run
+    const int srow = tid >> 3;      // 0..31
+
+    const int cin_steps = p.Cin / CBK;
+    const int taps = p.transposed ? 1 : p.ksize * p.ksize * p.ksize;
+    const int n_iters_all = taps * cin_steps;
+    int it_begin = 0, it_end = n_iters_all;
+    int ztap = 0;
+    if (p.transposed) {
+        ztap = blockIdx.z;
+    } else if (p.splits > 1) {
+        const int s = blockIdx.z;
+        it_begin = (int)((int64_t)n_iters_all * s / p.splits);
+        it_end = (int)((int64_t)n_iters_all * (s + 1) / p.splits);
+    }
+
+    // decode the output (or, transposed, input) voxel of the A rows this thread stages
+    int vd[AR], vh[AR], vw[AR];
+    bool vok[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + srow + 32 * i;
+        vok[i] = m < p.M;
+        const int mm = vok[i] ? m : 0;
+        const int ow_ = p.transposed ? p.W : p.OW, oh_ = p.transposed ? p.H : p.OH;
+        vw[i] = mm % ow_;
+        vh[i] = (mm / ow_) % oh_;
+        vd[i] = mm / (ow_ * oh_);
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[AR], rb[BR];
+
+    auto load_tile = [&](int it) {
+        const int tap = p.transposed ? ztap : it / cin_steps;
+        const int ci0 = (p.transposed ? it : it % cin_steps) * CBK + chunk * 4;
+        const int kd = tap / (p.ksize * p.ksize), kh = (tap / p.ksize) % p.ksize, kw = tap % p.ksize;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            int id, ih, iw;
+            if (p.transposed) {
+                id = vd[i]; ih = vh[i]; iw = vw[i];
+            } else {
+                id = vd[i] * p.stride + kd - p.pad;
+                ih = vh[i] * p.stride + kh - p.pad;
+                iw = vw[i] * p.stride + kw - p.pad;
+            }
+            const bool ok = vok[i] && id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) ra[i] = *reinterpret_cast<const float4*>(p.in + ((int64_t)(id * p.H + ih) * p.W + iw) * p.Cin + ci0);
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int co = n0 + srow + 32 * i;
+            rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < p.Cout) rb[i] = *reinterpret_cast<const float4*>(p.w + ((int64_t)tap * p.Cout + co) * p.Cin + ci0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* a = As + buf * BM * CLD;
+        float* b = Bs + buf * BN * CLD;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) *reinterpret_cast<float4*>(a + (srow + 32 * i) * CLD + chunk * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i) *reinterpret_cast<float4*>(b + (srow + 32 * i) * CLD + chunk * 4) = rb[i];
+    };
+
+    if (it_begin < it_end) {
+        load_tile(it_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    const int frow = lane & 15, fk = (lane >> 4) * 4;
+    for (int it = it_begin; it < it_end; ++it) {
+        const int buf = (it - it_begin) & 1;
+        if (it + 1 < it_end) load_tile(it + 1);
+        const float* a = As + buf * BM * CLD + (wm * WM + frow) * CLD + fk;
+        const float* b = Bs + buf * BN * CLD + (wn * WN + frow) * CLD + fk;
+#pragma unroll
+        for (int kk = 0; kk < CBK; kk += 16) {
+            float fa[MT][4], fb[NT][4];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const float4 v = *reinterpret_cast<const float4*>(a + t * 16 * CLD + kk);
+                fa[t][0] = v.x; fa[t][1] = v.y; fa[t][2] = v.z; fa[t][3] = v.w;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float4 v = *reinterpret_cast<const float4*>(b + t * 16 * CLD + kk);
+                fb[t][0] = v.x; fb[t][1] = v.y; fb[t][2] = v.z; fb[t][3] = v.w;
+            }
+            // j outermost: MT*NT independent accumulators between two dependent MFMAs (40-cycle dependent latency)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ta = 0; ta < MT; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < NT; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ta][j], fb[tb][j], acc[ta][tb], 0, 0, 0);
+        }
+        if (it + 1 < it_end) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg ----
+    const bool raw = (!p.transposed && p.splits > 1);
+    float* dst = raw ? p.partial + (int64_t)blockIdx.z * p.M * p.Cout : p.out;
+#pragma unroll
+    for (int ta = 0; ta < MT; ++ta) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * WM + ta * 16 + (lane >> 4) * 4 + r;
+            if (m >= p.M) continue;
+            int64_t orow = m;
+            if (p.transposed) {
+                const int iw = m % p.W, ih = (m / p.W) % p.H, id = m / (p.W * p.H);
+                const int kd = ztap >> 2, kh = (ztap >> 1) & 1, kw = ztap & 1;
+                orow = ((int64_t)(2 * id + kd) * p.OH + (2 * ih + kh)) * p.OW + (2 * iw + kw);
+            }
+#pragma unroll
+            for (int tb = 0; tb < NT; ++tb) {
+                const int co = n0 + wn * WN + tb * 16 + (lane & 15);
+                if (co >= p.Cout) continue;
+                float v = acc[ta][tb][r];
+                if (!raw) {
+                    if (p.scale) v = v * p.scale[co] + p.shift[co];
+                    if (p.relu == 2) v = fmaxf(v, 0.0f);
+                    if (p.res) v = v + p.res[orow * p.Cout + co];
+                    if (p.relu == 1) v = fmaxf(v, 0.0f);
+                }
+                dst[orow * p.Cout + co] = v;
+            }
+        }
+    }
+}
+
+// fixed-order reduction of the split-K partials + epilogue
+__global__ __launch_bounds__(256) void k_conv3d_splitk_reduce(const float* __restrict__ partial, int splits, int64_t MN, int Cout,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              const float* __restrict__ res, int relu, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= MN) return;
+    float v = partial[i];
+    for (int s = 1; s < splits; ++s) v = v + partial[(int64_t)s * MN + i];
+    const int co = (int)(i % Cout);
+    if (scale) v = v * scale[co] + shift[co];
+    if (relu == 2) v = fmaxf(v, 0.0f);
+    if (res) v = v + res[i];
+    if (relu == 1) v = fmaxf(v, 0.0f);
+    out[i] = v;
+}
+
+extern "C" int64_t ndet_conv3d_workspace_bytes(int D, int H, int W, int Cin, int Cout, int ksize, int stride, int splits) {
+    if (splits <= 1) return 0;
+    const int pad = ksize / 2;
+    const int64_t od = (D + 2 * pad - ksize) / stride + 1, oh = (H + 2 * pad - ksize) / stride + 1, ow = (W + 2 * pad - ksize) / stride + 1;
+    return od * oh * ow * (int64_t)Cout * splits * 4;
+}
+
+extern "C" int ndet_conv3d_ndhwc(const float* in, const float* w_packed, float* out, int D, int H, int W, int Cin, int Cout, int ksize,
+                                 int stride, int transposed, const float* scale, const float* shift, const float* residual, int relu,
+                                 int splits, int tile, void* workspace, void* stream) {
+    const char* fn = "ndet_conv3d_ndhwc";
+    NDET_REQUIRE(in && w_packed && out, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
+    NDET_REQUIRE((scale == nullptr) == (shift == nullptr), NDET_E_INVALID, "%s: scale and shift go together", fn);
+    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
+    NDET_REQUIRE(Cin % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
+    NDET_REQUIRE((((uintptr_t)in | (uintptr_t)w_packed) & 15) == 0, NDET_E_UNSUPPORTED, "%s: in / weights must be 16-byte aligned", fn);
+    Conv3dParams p;
+    p.in = in; p.w = w_packed; p.out = out; p.scale = scale; p.shift = shift; p.res = residual; p.partial = (float*)workspace;
+    p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu; p.transposed = transposed;
+    if (transposed) {
+        NDET_REQUIRE(ksize == 2 && stride == 2, NDET_E_UNSUPPORTED, "%s: transposed conv supports kernel 2 stride 2 only", fn);
+        p.ksize = 2; p.stride = 2; p.pad = 0;
+        p.OD = 2 * D; p.OH = 2 * H; p.OW = 2 * W;
+        p.M = D * H * W;
+        p.splits = 1;
+    } else {
+        NDET_REQUIRE((ksize == 3 || ksize == 1) && (stride == 1 || stride == 2), NDET_E_UNSUPPORTED, "%s: kernel %d stride %d unsupported", fn, ksize, stride);
+        p.ksize = ksize; p.stride = stride; p.pad = ksize / 2;
+        p.OD = (D + 2 * p.pad - ksize) / stride + 1;
+        p.OH = (H + 2 * p.pad - ksize) / stride + 1;
+        p.OW = (W + 2 * p.pad - ksize) / stride + 1;
+        p.M = p.OD * p.OH * p.OW;
+        p.splits = splits < 1 ? 1 : splits;
+        const int iters = ksize * ksize * ksize * (Cin / CBK);
+        NDET_REQUIRE(p.splits <= iters, NDET_E_INVALID, "%s: splits=%d exceeds the %d K steps", fn, p.splits, iters);
+        NDET_REQUIRE(p.splits == 1 || workspace != nullptr, NDET_E_INVALID, "%s: split-K needs a workspace", fn);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int zdim = transposed ? 8 : p.splits;
+    // tile choice: big tiles when they still fill the chip, small ones otherwise
+    const int64_t big_tiles = (int64_t)((p.M + 127) / 128) * ((Cout + 127) / 128) * zdim;
+    const bool big = tile == 128 || (tile == 0 && big_tiles >= 192 && Cout >= 128);
+    if (big) {
+        dim3 grid((p.M + 127) / 128, (Cout + 127) / 128, zdim);
+        const size_t lds = (size_t)2 * (128 + 128) * CLD * sizeof(float);
+        static bool attr_set = false;  // 72 KiB of dynamic LDS: above the 64 KiB default cap
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_conv3d_igemm<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_conv3d_igemm<128, 128>), grid, dim3(256), lds, st, p);
+    } else {
+        dim3 grid((p.M + 63) / 64, (Cout + 63) / 64, zdim);
+        const size_t lds = (size_t)2 * (64 + 64) * CLD * sizeof(float);
+        hipLaunchKernelGGL((k_conv3d_igemm<64, 64>), grid, dim3(256), lds, st, p);
+    }
+    NDET_CHECK_LAUNCH(fn);
+    if (!transposed && p.splits > 1) {
+        const int64_t mn = (int64_t)p.M * Cout;
+        hipLaunchKernelGGL(k_conv3d_splitk_reduce, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, p.partial, p.splits, mn, Cout, scale,
+                           shift, residual, relu, out);
+        NDET_CHECK_LAUNCH(fn);
+    }
+    return NDET_OK;
+}

@@ -118,8 +118,9 @@ class nerfdet(BaseDetector):
         for b, img_meta in enumerate(img_metas):
             feat = x[b * n_v:(b + 1) * n_v]
             dn = denorm.reshape([-1] + list(denorm.shape)[2:])
+            # inference: channels-last volume straight into the MFMA conv neck; training: NCDHW for the library convs
             out = extract_volume(feat, dn, img_meta, self.n_voxels, self.voxel_size, self.mapping, self.nerf_mlp,
-                                 stride=stride, channels_last_out=False)
+                                 stride=stride, channels_last_out=not torch.is_grad_enabled())
             if mode == "train" or self.render_testing:
                 from .rays import render_rays
                 rgb_preds.append(render_rays(ray_batch, None, None, out["feature_2d"], dn, self.aabb, self.near_far_range,

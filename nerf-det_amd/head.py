@@ -14,6 +14,7 @@ from torch import nn
 
 from . import losses  # noqa: F401  (registers the loss types the head builds)
 from . import ops
+from .conv3d import conv3d_ndhwc, packed, to_ndhwc
 from .nms import aligned_3d_nms
 from .registry import HEADS, build_loss
 
@@ -69,7 +70,18 @@ class ScanNetImVoxelHeadV2(nn.Module):
 
     # ---- forward ---------------------------------------------------------------------------
     def forward_single(self, x, scale):
+        if x.is_cuda and not self.training and not torch.is_grad_enabled() and x.shape[1] % 32 == 0:
+            return self.forward_single_hip(x, scale)
         return self.centerness_conv(x), torch.exp(scale(self.reg_conv(x))), self.cls_conv(x)
+
+    def forward_single_hip(self, x, scale):
+        """The three 3x3x3 convs share their input: one MFMA conv with Cout = 1 + n_reg + n_classes (cls bias in the
+        epilogue shift), then channel views.  imvoxel_head_v2.py:444-449."""
+        pk = packed([self.centerness_conv, self.reg_conv, self.cls_conv])
+        n_reg = self.reg_conv.out_channels
+        outs = [conv3d_ndhwc(to_ndhwc(x[b].float()), pk).permute(3, 0, 1, 2) for b in range(x.shape[0])]
+        o = outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
+        return o[:, :1], torch.exp(scale(o[:, 1:1 + n_reg])), o[:, 1 + n_reg:]
 
     def forward(self, x):
         outs = [self.forward_single(f, s) for f, s in zip(x, self.scales)]

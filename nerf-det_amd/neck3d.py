@@ -1,10 +1,15 @@
 """A13: 3-level 3D ResNet-FPN over the voxel volume -- mirror of ``FastIndoorImVoxelNeck`` and
 ``BasicBlock3dV2`` (mmdet3d/models/necks/imvoxelnet.py:8-67, 233-260), same state-dict keys.
-Dense contraction: library (MIOpen) convolutions for now; measured rates in DESIGN.md."""
+
+Inference (``eval()`` on the GPU) runs the hand-written fp32-MFMA implicit-GEMM convolution of csrc/conv3d_kernels.hip
+with BatchNorm / ReLU / residual adds fused into its epilogue, channels-last end to end.  Training mode (batch
+statistics, autograd) goes through the vendor library modules below."""
 from __future__ import annotations
 
+import torch
 from torch import nn
 
+from .conv3d import conv3d_ndhwc, packed, to_ndhwc
 from .registry import NECKS
 
 
@@ -26,6 +31,12 @@ class BasicBlock3dV2(nn.Module):
         out = self.norm2(self.conv2(out))
         idt = self.downsample(x) if self.stride != 1 else x
         return self.relu(out + idt)
+
+    def forward_ndhwc(self, x):
+        """x (D,H,W,C) -> (D',H',W',C'); eval-mode BN folded, ``relu(bn2(conv2(.)) + identity)`` in one epilogue."""
+        y = conv3d_ndhwc(x, packed([self.conv1], self.norm1), relu=1)
+        idt = x if self.stride == 1 else conv3d_ndhwc(x, packed([self.downsample[0]], self.downsample[1]))
+        return conv3d_ndhwc(y, packed([self.conv2], self.norm2), residual=idt, relu=1)
 
 
 def _conv_bn_relu(cin, cout):
@@ -58,6 +69,32 @@ class FastIndoorImVoxelNeck(nn.Module):
         pass
 
     def forward(self, x):
+        # the MFMA kernel steps K by 32 input channels; every shipped config (256/512/1024) qualifies
+        if x.is_cuda and not self.training and not torch.is_grad_enabled() and x.shape[1] % 32 == 0:
+            return self.forward_hip(x)
+        return self.forward_library(x)
+
+    def forward_hip(self, x):
+        """(B,C,X,Y,Z) -> 3 x (B,128,X_i,Y_i,Z_i), logical NCDHW views of channels-last results."""
+        per_level = [[] for _ in range(self.n_scales)]
+        for b in range(x.shape[0]):
+            t = to_ndhwc(x[b].float())
+            downs = []
+            for i in range(self.n_scales):
+                for blk in getattr(self, f"down_layer_{i}"):
+                    t = blk.forward_ndhwc(t)
+                downs.append(t)
+            for i in range(self.n_scales - 1, -1, -1):
+                if i < self.n_scales - 1:
+                    up = getattr(self, f"up_block_{i + 1}")
+                    t = conv3d_ndhwc(t, packed([up[0]], up[1]), relu=1)
+                    # x = down_outs[i] + up(x): ReLU first, then the skip add (imvoxelnet.py:30-31)
+                    t = conv3d_ndhwc(t, packed([up[3]], up[4]), residual=downs[i], relu=2)
+                ob = getattr(self, f"out_block_{i}")
+                per_level[i].append(conv3d_ndhwc(t, packed([ob[0]], ob[1]), relu=1).permute(3, 0, 1, 2))
+        return [lv[0].unsqueeze(0) if len(lv) == 1 else torch.stack(lv) for lv in per_level]
+
+    def forward_library(self, x):
         downs = []
         for i in range(self.n_scales):
             x = getattr(self, f"down_layer_{i}")(x)
