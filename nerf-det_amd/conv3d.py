@@ -87,14 +87,18 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
         assert residual.shape == out.shape and residual.is_contiguous()
     lib = _lib.load()
     m = d * h * w if tr else od * oh * ow
-    if splits == 0:  # fill the 256 CUs: split K when the output tile grid alone cannot
-        splits = 1
-        if not tr:
-            t = tile or (128 if ((m + 127) // 128) * ((cout + 127) // 128) >= 192 and cout >= 128 else 64)
-            tiles = ((m + t - 1) // t) * ((cout + t - 1) // t)
-            iters = k ** 3 * (cin // 32)
-            if tiles < 256:
-                splits = max(1, min(8, (384 + tiles - 1) // tiles, iters // 8))
+    if splits == 0 or tile == 0:
+        # measured on MI355X (tools/tune_conv3d.py): 128^2 tiles once there are >= 256 of them, else 64^2; split K until
+        # the grid holds ~1200 (128^2) / ~2400 (64^2) workgroups, keeping >= 8 K steps per split
+        if tile == 0:
+            tile = 128 if ((m + 127) // 128) * ((cout + 127) // 128) >= 256 and cout >= 128 else 64
+        if splits == 0:
+            splits = 1
+            if not tr:
+                tiles = ((m + tile - 1) // tile) * ((cout + tile - 1) // tile)
+                iters = k ** 3 * (cin // 32)
+                want = 1200 if tile == 128 else 2400
+                splits = max(1, min(8, (want + tiles - 1) // tiles, iters // 8))
     ws = None
     if splits > 1:
         ws = torch.empty((int(lib.ndet_conv3d_workspace_bytes(d, h, w, cin, cout, k, s, splits)),), dtype=torch.uint8, device=x.device)

@@ -91,9 +91,13 @@ __global__ __launch_bounds__(256) void k_conv3d_igemm(const Conv3dParams p) {
 
     float4 ra[AR], rb[BR];
 
-    auto load_tile = [&](int it) {
-        const int tap = p.transposed ? ztap : it / cin_steps;
-        const int ci0 = (p.transposed ? it : it % cin_steps) * CBK + chunk * 4;
+    // Per-tap state, recomputed only when the K walk enters a new tap: for each staged A row the address of the
+    // neighbour voxel's channel run (or null outside the grid), for each staged B row the weight row.
+    const float* arow[AR];
+    const float* brow[BR];
+    int cur_tap = -1;
+    auto enter_tap = [&](int tap) {
+        cur_tap = tap;
         const int kd = tap / (p.ksize * p.ksize), kh = (tap / p.ksize) % p.ksize, kw = tap % p.ksize;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
@@ -106,14 +110,27 @@ __global__ __launch_bounds__(256) void k_conv3d_igemm(const Conv3dParams p) {
                 iw = vw[i] * p.stride + kw - p.pad;
             }
             const bool ok = vok[i] && id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) ra[i] = *reinterpret_cast<const float4*>(p.in + ((int64_t)(id * p.H + ih) * p.W + iw) * p.Cin + ci0);
+            arow[i] = ok ? p.in + ((int64_t)(id * p.H + ih) * p.W + iw) * p.Cin + chunk * 4 : nullptr;
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
             const int co = n0 + srow + 32 * i;
+            brow[i] = co < p.Cout ? p.w + ((int64_t)tap * p.Cout + co) * p.Cin + chunk * 4 : nullptr;
+        }
+    };
+    auto load_tile = [&](int it) {
+        const int tap = p.transposed ? ztap : it / cin_steps;
+        if (tap != cur_tap) enter_tap(tap);
+        const int ci0 = (p.transposed ? it : it - tap * cin_steps) * CBK;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (arow[i]) ra[i] = *reinterpret_cast<const float4*>(arow[i] + ci0);
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
             rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (co < p.Cout) rb[i] = *reinterpret_cast<const float4*>(p.w + ((int64_t)tap * p.Cout + co) * p.Cin + ci0);
+            if (brow[i]) rb[i] = *reinterpret_cast<const float4*>(brow[i] + ci0);
         }
     };
     auto store_tile = [&](int buf) {

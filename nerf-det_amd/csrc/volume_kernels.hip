@@ -23,10 +23,10 @@ extern "C" const char* ndet_last_error(void) { return g_err; }
 
 #define VOX_PER_TILE 16  // one workgroup = 4 waves x 4 voxels = 16 consecutive voxels (one z column at Z=16)
 #ifndef GATHER_BATCH
-#define GATHER_BATCH 8  // independent 1-KiB row loads a wave keeps in flight per voxel
+#define GATHER_BATCH 4  // independent 1-KiB row loads a wave keeps in flight per voxel (tools/tune_k1.py: 4 beats 8/12/16)
 #endif
 #ifndef K1_MIN_WAVES
-#define K1_MIN_WAVES 1  // __launch_bounds__ 2nd argument (waves per SIMD) for K1; tuned with tools/tune_k1.py
+#define K1_MIN_WAVES 6  // __launch_bounds__ 2nd argument (waves per SIMD) for K1; tuned with tools/tune_k1.py
 #endif
 
 // ------------------------------------------------------------------------------------------

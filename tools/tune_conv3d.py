@@ -1,0 +1,58 @@
+"""Scratch tuner (GPU box): times the MFMA conv3d on every layer shape of the cfg2 neck/head across tile / split-K choices."""
+import os, sys, itertools
+import torch
+from torch import nn
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nerfdet_amd.conv3d import conv3d_ndhwc, packed
+
+LAYERS = [  # name, cin, cout, grid(in), k, stride, transposed
+    ("down0.conv 256->256 @40x40x16", 256, 256, (40, 40, 16), 3, 1, False),
+    ("out0 256->128 @40x40x16", 256, 128, (40, 40, 16), 3, 1, False),
+    ("down1.conv1 256->512 s2", 256, 512, (40, 40, 16), 3, 2, False),
+    ("down1.conv2 512->512 @20x20x8", 512, 512, (20, 20, 8), 3, 1, False),
+    ("down1.ds 1x1 s2 256->512", 256, 512, (40, 40, 16), 1, 2, False),
+    ("out1 512->128 @20x20x8", 512, 128, (20, 20, 8), 3, 1, False),
+    ("down2.conv1 512->1024 s2", 512, 1024, (20, 20, 8), 3, 2, False),
+    ("down2.conv2 1024->1024 @10x10x4", 1024, 1024, (10, 10, 4), 3, 1, False),
+    ("out2 1024->128 @10x10x4", 1024, 128, (10, 10, 4), 3, 1, False),
+    ("up2.convT 1024->512", 1024, 512, (10, 10, 4), 2, 2, True),
+    ("up1.convT 512->256", 512, 256, (20, 20, 8), 2, 2, True),
+    ("head 128->25 @40x40x16", 128, 25, (40, 40, 16), 3, 1, False),
+]
+
+def main():
+    dev = torch.device("cuda")
+    for name, cin, cout, grid, k, s, tr in LAYERS:
+        conv = (nn.ConvTranspose3d(cin, cout, 2, 2, bias=False) if tr else nn.Conv3d(cin, cout, k, s, k // 2, bias=False)).to(dev)
+        bn = nn.BatchNorm3d(cout).to(dev).eval()
+        pk = packed([conv], bn)
+        x = torch.randn(*grid, cin, device=dev)
+        od = [2 * g for g in grid] if tr else [(g + 2 * (k // 2) - k) // s + 1 for g in grid]
+        flops = 2 * od[0] * od[1] * od[2] * cout * cin * (1 if tr else k ** 3)
+        best = None
+        for tile, splits in itertools.product((64, 128), (1,) if tr else (1, 2, 3, 4, 6, 8)):
+            if splits > k ** 3 * (cin // 32):
+                continue
+            try:
+                for _ in range(2):
+                    conv3d_ndhwc(x, pk, relu=1, splits=splits, tile=tile)
+                ts = []
+                for _ in range(5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); conv3d_ndhwc(x, pk, relu=1, splits=splits, tile=tile); e1.record(); torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                t = sorted(ts)[2]
+            except Exception as e:
+                print(name, tile, splits, "failed", repr(e)[:100]); continue
+            if best is None or t < best[0]:
+                best = (t, tile, splits)
+            print(f"  {name:36s} tile={tile:3d} splits={splits} {t*1e3:8.1f} us {flops/t/1e9:7.1f} TF", flush=True)
+        auto = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); conv3d_ndhwc(x, pk, relu=1); e1.record(); torch.cuda.synchronize(); auto.append(e0.elapsed_time(e1))
+        print(f"BEST {name:36s} tile={best[1]} splits={best[2]} {best[0]*1e3:8.1f} us {flops/best[0]/1e9:7.1f} TF | auto {sorted(auto)[2]*1e3:8.1f} us  ({flops/1e9:.1f} GF)", flush=True)
+
+if __name__ == "__main__":
+    main()
