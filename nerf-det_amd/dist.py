@@ -1,0 +1,73 @@
+"""One-process-per-GPU plumbing: scenes are independent units, so inference shards by scene
+with no data-path collective; the only exchanges are the result gather at the end (``mmdet.apis.multi_gpu_test`` /
+``collect_results_gpu`` semantics, tools/test.py:131-136) and, in training, DDP's gradient all-reduce plus the scalar
+``reduce_mean`` of imvoxel_head_v2.py:175.  Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests."""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_dist(backend: str = "nccl") -> tuple:
+    """tools/train.py:98-102 ``init_dist('pytorch')``: env:// rendezvous, device = LOCAL_RANK."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(backend)
+    return rank, world, local
+
+
+def get_dist_info() -> tuple:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_indices(n: int, rank: int, world: int) -> List[int]:
+    """Scene indices of this rank: ``DistributedSampler(shuffle=False)`` -- round-robin, padded by wrapping so every
+    rank runs the same number of steps (the padding is dropped again by :func:`collect_results`)."""
+    per = (n + world - 1) // world
+    idx = list(range(n)) + list(range(per * world - n))
+    return idx[rank:per * world:world]
+
+
+def collect_results(part: Sequence, size: int) -> List:
+    """All ranks' per-scene results merged back into dataset order on rank 0 (``collect_results_gpu``):
+    interleave the rank-local lists, drop the sampler padding.  Returns ``None`` on other ranks."""
+    rank, world = get_dist_info()
+    if world == 1:
+        return list(part)[:size]
+    parts = [None] * world
+    dist.all_gather_object(parts, list(part))
+    if rank != 0:
+        return None
+    ordered = []
+    for items in zip(*parts):
+        ordered.extend(items)
+    return ordered[:size]
+
+
+def multi_gpu_test(model: Callable, scenes: Sequence, to_device: Callable = lambda b: b) -> List:
+    """Each rank runs ``model(return_loss=False, **scene)`` on its shard; rank 0 gets every result in order."""
+    rank, world = get_dist_info()
+    out = []
+    with torch.no_grad():
+        for i in shard_indices(len(scenes), rank, world):
+            out.extend(model(return_loss=False, **to_device(scenes[i])))
+    return collect_results(out, len(scenes))
+
+
+def max_over_ranks(seconds: float, device=None) -> float:
+    """bench.py timing: the step time of the job is the slowest rank's."""
+    rank, world = get_dist_info()
+    if world == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
