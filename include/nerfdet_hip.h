@@ -152,6 +152,16 @@ int ndet_conv3d_ndhwc(const float* in, const float* w_packed, float* out, int D,
                       int ksize, int stride, int transposed, const float* scale, const float* shift,
                       const float* residual, int relu, int splits, int tile, void* workspace, void* stream);
 
+/* Generic form of the same kernel: per-axis kernel / stride / zero-pad (3 ints each, HOST memory, order D,H,W).
+ * A batch of 2D feature maps (N,H,W,C) is the case D = N, kernel[0] = 1, pad[0] = 0 -- used for the ResNet/FPN convolutions
+ * (conv + eval-BatchNorm + ReLU + residual in one pass; third-party mmdet ResNet/FPN, SURVEY.md appendix C, called at
+ * mmdet3d/models/detectors/nerfdet.py:140-142).  w_packed (kd*kh*kw, Cout, Cin).  Other arguments as ndet_conv3d_ndhwc;
+ * split-K workspace = splits * OD*OH*OW*Cout * 4 bytes. */
+int ndet_conv_ndhwc(const float* in, const float* w_packed, float* out, int D, int H, int W, int Cin, int Cout,
+                    const int* kernel_host, const int* stride_host, const int* pad_host, const float* scale,
+                    const float* shift, const float* residual, int relu, int splits, int tile, void* workspace,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

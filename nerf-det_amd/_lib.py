@@ -40,6 +40,8 @@ SIGNATURES = {
                              _P, c_int, c_int, c_int, c_int64, c_int64, _P, _P, _P], c_int),
     "ndet_composite": ([_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
     "ndet_conv3d_workspace_bytes": ([c_int] * 8, c_int64),
+    "ndet_conv_ndhwc": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                         ctypes.POINTER(c_int), _P, _P, _P, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_conv3d_ndhwc": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_int,
                            _P, _P], c_int),
 }

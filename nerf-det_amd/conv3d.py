@@ -6,6 +6,7 @@ uses), followed by optional residual add and ReLU -- replacing nn.Conv3d/ConvTra
 mmdet3d/models/necks/imvoxelnet.py:36-67,233-260."""
 from __future__ import annotations
 
+import ctypes
 from ctypes import c_void_p
 from typing import Optional, Sequence
 
@@ -23,7 +24,11 @@ def _ptr(t):
 
 
 def pack_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
-    """Conv3d weight (Cout,Cin,k,k,k) -> (k^3, Cout, Cin); ConvTranspose3d weight (Cin,Cout,2,2,2) -> (8, Cout, Cin)."""
+    """Conv3d weight (Cout,Cin,k,k,k) -> (k^3, Cout, Cin); Conv2d weight (Cout,Cin,kh,kw) -> (kh*kw, Cout, Cin);
+    ConvTranspose3d weight (Cin,Cout,2,2,2) -> (8, Cout, Cin)."""
+    if w.dim() == 4:
+        cout, cin = w.shape[:2]
+        return w.permute(2, 3, 0, 1).reshape(-1, cout, cin).contiguous().float()
     if transposed:
         cin, cout = w.shape[:2]
         return w.permute(2, 3, 4, 1, 0).reshape(-1, cout, cin).contiguous().float()
@@ -31,7 +36,7 @@ def pack_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
     return w.permute(2, 3, 4, 0, 1).reshape(-1, cout, cin).contiguous().float()
 
 
-def fold_bn(bn: Optional[nn.BatchNorm3d], bias: Optional[torch.Tensor], cout: int, device):
+def fold_bn(bn, bias: Optional[torch.Tensor], cout: int, device):
     """(scale, shift) of the fused epilogue, or (None, None) when there is nothing to apply."""
     if bn is None and bias is None:
         return None, None
@@ -63,8 +68,9 @@ def packed(convs: Sequence[nn.Module], bn: Optional[nn.BatchNorm3d] = None):
         bias = torch.cat([c.bias.detach() if c.bias is not None else torch.zeros(c.weight.shape[1 if tr else 0], device=w.device)
                           for c in convs])
     scale, shift = fold_bn(bn, bias, cout, w.device)
-    val = dict(w=w, scale=scale, shift=shift, cout=cout, cin=w.shape[2], ksize=convs[0].kernel_size[0], stride=convs[0].stride[0],
-               transposed=tr)
+    c0 = convs[0]
+    val = dict(w=w, scale=scale, shift=shift, cout=cout, cin=w.shape[2], ksize=c0.kernel_size[0], stride=c0.stride[0], transposed=tr,
+               kernel=tuple(c0.kernel_size), strides=tuple(c0.stride), pads=tuple(c0.padding), ndim=len(c0.kernel_size))
     _cache[key] = (stamp, val)
     return val
 
@@ -105,6 +111,34 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
     st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     check(lib.ndet_conv3d_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), d, h, w, cin, cout, k, s, int(tr), _ptr(pk["scale"]), _ptr(pk["shift"]),
                                 _ptr(residual), relu, splits, tile, _ptr(ws), st), "conv3d_ndhwc")
+    return out
+
+
+def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = None, relu: int = 0, splits: int = 0, tile: int = 0):
+    """Batch of 2D maps, x (N,H,W,Cin) contiguous fp32 -> (N,OH,OW,Cout): Conv2d (+ eval BatchNorm2d / bias) + ReLU +
+    residual in one pass of the MFMA kernel (the batch is the kernel's depth axis with extent-1 taps)."""
+    if not x.is_cuda:
+        raise RuntimeError("nerfdet_amd.conv3d: tensors must live on the GPU (no CPU fallback)")
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32 and pk["ndim"] == 2
+    n, h, w, cin = x.shape
+    assert cin == pk["cin"], (cin, pk["cin"])
+    (kh, kw), (sh, sw), (ph, pw), cout = pk["kernel"], pk["strides"], pk["pads"], pk["cout"]
+    oh, ow = (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
+    out = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous()
+    m = n * oh * ow
+    if tile == 0:
+        tile = 128 if ((m + 127) // 128) * ((cout + 127) // 128) >= 256 and cout >= 128 else 64
+    if splits == 0:
+        tiles = ((m + tile - 1) // tile) * ((cout + tile - 1) // tile)
+        iters = kh * kw * (cin // 32)
+        splits = max(1, min(8, ((1200 if tile == 128 else 2400) + tiles - 1) // tiles, iters // 8))
+    ws = torch.empty((m * cout * splits * 4,), dtype=torch.uint8, device=x.device) if splits > 1 else None
+    i3 = lambda a, b, c: (ctypes.c_int * 3)(a, b, c)
+    st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    check(_lib.load().ndet_conv_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), n, h, w, cin, cout, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw),
+                                      _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), relu, splits, tile, _ptr(ws), st), "conv2d_nhwc")
     return out
 
 

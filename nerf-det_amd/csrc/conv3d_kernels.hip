@@ -33,7 +33,9 @@ struct Conv3dParams {
     float* partial;       // split-K workspace (splits, M, Cout) or null
     int D, H, W, Cin;
     int OD, OH, OW, Cout;
-    int ksize, stride, pad;
+    int kd, kh, kw;       // kernel extent per axis (2D convolution: D = batch, kd = 1)
+    int sd, sh, sw;       // stride per axis
+    int pd, ph, pw;       // zero padding per axis
     int relu;             // 0 none, 1 ReLU last (after the residual add), 2 ReLU before the residual add
     int transposed;       // 1: ConvTranspose3d k=2 s=2 (blockIdx.z = tap)
     int splits;           // split-K factor (blockIdx.z = split) when !transposed
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void k_conv3d_igemm(const Conv3dParams p) {
     const int srow = tid >> 3;      // 0..31
 
     const int cin_steps = p.Cin / CBK;
-    const int taps = p.transposed ? 1 : p.ksize * p.ksize * p.ksize;
+    const int taps = p.transposed ? 1 : p.kd * p.kh * p.kw;
     const int n_iters_all = taps * cin_steps;
     int it_begin = 0, it_end = n_iters_all;
     int ztap = 0;
@@ -98,16 +100,16 @@ __global__ __launch_bounds__(256) void k_conv3d_igemm(const Conv3dParams p) {
     int cur_tap = -1;
     auto enter_tap = [&](int tap) {
         cur_tap = tap;
-        const int kd = tap / (p.ksize * p.ksize), kh = (tap / p.ksize) % p.ksize, kw = tap % p.ksize;
+        const int kd = tap / (p.kh * p.kw), kh = (tap / p.kw) % p.kh, kw = tap % p.kw;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             int id, ih, iw;
             if (p.transposed) {
                 id = vd[i]; ih = vh[i]; iw = vw[i];
             } else {
-                id = vd[i] * p.stride + kd - p.pad;
-                ih = vh[i] * p.stride + kh - p.pad;
-                iw = vw[i] * p.stride + kw - p.pad;
+                id = vd[i] * p.sd + kd - p.pd;
+                ih = vh[i] * p.sh + kh - p.ph;
+                iw = vw[i] * p.sw + kw - p.pw;
             }
             const bool ok = vok[i] && id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
             arow[i] = ok ? p.in + ((int64_t)(id * p.H + ih) * p.W + iw) * p.Cin + chunk * 4 : nullptr;
@@ -228,49 +230,11 @@ __global__ __launch_bounds__(256) void k_conv3d_splitk_reduce(const float* __res
     out[i] = v;
 }
 
-extern "C" int64_t ndet_conv3d_workspace_bytes(int D, int H, int W, int Cin, int Cout, int ksize, int stride, int splits) {
-    if (splits <= 1) return 0;
-    const int pad = ksize / 2;
-    const int64_t od = (D + 2 * pad - ksize) / stride + 1, oh = (H + 2 * pad - ksize) / stride + 1, ow = (W + 2 * pad - ksize) / stride + 1;
-    return od * oh * ow * (int64_t)Cout * splits * 4;
-}
-
-extern "C" int ndet_conv3d_ndhwc(const float* in, const float* w_packed, float* out, int D, int H, int W, int Cin, int Cout, int ksize,
-                                 int stride, int transposed, const float* scale, const float* shift, const float* residual, int relu,
-                                 int splits, int tile, void* workspace, void* stream) {
-    const char* fn = "ndet_conv3d_ndhwc";
-    NDET_REQUIRE(in && w_packed && out, NDET_E_INVALID, "%s: null pointer", fn);
-    NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
-    NDET_REQUIRE((scale == nullptr) == (shift == nullptr), NDET_E_INVALID, "%s: scale and shift go together", fn);
-    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
-    NDET_REQUIRE(Cin % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
-    NDET_REQUIRE((((uintptr_t)in | (uintptr_t)w_packed) & 15) == 0, NDET_E_UNSUPPORTED, "%s: in / weights must be 16-byte aligned", fn);
-    Conv3dParams p;
-    p.in = in; p.w = w_packed; p.out = out; p.scale = scale; p.shift = shift; p.res = residual; p.partial = (float*)workspace;
-    p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu; p.transposed = transposed;
-    if (transposed) {
-        NDET_REQUIRE(ksize == 2 && stride == 2, NDET_E_UNSUPPORTED, "%s: transposed conv supports kernel 2 stride 2 only", fn);
-        p.ksize = 2; p.stride = 2; p.pad = 0;
-        p.OD = 2 * D; p.OH = 2 * H; p.OW = 2 * W;
-        p.M = D * H * W;
-        p.splits = 1;
-    } else {
-        NDET_REQUIRE((ksize == 3 || ksize == 1) && (stride == 1 || stride == 2), NDET_E_UNSUPPORTED, "%s: kernel %d stride %d unsupported", fn, ksize, stride);
-        p.ksize = ksize; p.stride = stride; p.pad = ksize / 2;
-        p.OD = (D + 2 * p.pad - ksize) / stride + 1;
-        p.OH = (H + 2 * p.pad - ksize) / stride + 1;
-        p.OW = (W + 2 * p.pad - ksize) / stride + 1;
-        p.M = p.OD * p.OH * p.OW;
-        p.splits = splits < 1 ? 1 : splits;
-        const int iters = ksize * ksize * ksize * (Cin / CBK);
-        NDET_REQUIRE(p.splits <= iters, NDET_E_INVALID, "%s: splits=%d exceeds the %d K steps", fn, p.splits, iters);
-        NDET_REQUIRE(p.splits == 1 || workspace != nullptr, NDET_E_INVALID, "%s: split-K needs a workspace", fn);
-    }
-    hipStream_t st = (hipStream_t)stream;
-    const int zdim = transposed ? 8 : p.splits;
-    // tile choice: big tiles when they still fill the chip, small ones otherwise
-    const int64_t big_tiles = (int64_t)((p.M + 127) / 128) * ((Cout + 127) / 128) * zdim;
-    const bool big = tile == 128 || (tile == 0 && big_tiles >= 192 && Cout >= 128);
+static int conv_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn) {
+    const int Cout = p.Cout;
+    const int zdim = p.transposed ? 8 : p.splits;
+    const int64_t big_tiles = (int64_t)((p.M + 127) / 128) * ((Cout + 127) / 128);
+    const bool big = tile == 128 || (tile == 0 && big_tiles >= 256 && Cout >= 128);
     if (big) {
         dim3 grid((p.M + 127) / 128, (Cout + 127) / 128, zdim);
         const size_t lds = (size_t)2 * (128 + 128) * CLD * sizeof(float);
@@ -287,11 +251,76 @@ extern "C" int ndet_conv3d_ndhwc(const float* in, const float* w_packed, float* 
         hipLaunchKernelGGL((k_conv3d_igemm<64, 64>), grid, dim3(256), lds, st, p);
     }
     NDET_CHECK_LAUNCH(fn);
-    if (!transposed && p.splits > 1) {
+    if (!p.transposed && p.splits > 1) {
         const int64_t mn = (int64_t)p.M * Cout;
-        hipLaunchKernelGGL(k_conv3d_splitk_reduce, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, p.partial, p.splits, mn, Cout, scale,
-                           shift, residual, relu, out);
+        hipLaunchKernelGGL(k_conv3d_splitk_reduce, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, p.partial, p.splits, mn, Cout, p.scale,
+                           p.shift, p.res, p.relu, p.out);
         NDET_CHECK_LAUNCH(fn);
     }
     return NDET_OK;
+}
+
+extern "C" int ndet_conv_ndhwc(const float* in, const float* w_packed, float* out, int D, int H, int W, int Cin, int Cout,
+                               const int* kernel, const int* stride, const int* pad, const float* scale, const float* shift,
+                               const float* residual, int relu, int splits, int tile, void* workspace, void* stream) {
+    const char* fn = "ndet_conv_ndhwc";
+    NDET_REQUIRE(in && w_packed && out && kernel && stride && pad, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
+    NDET_REQUIRE((scale == nullptr) == (shift == nullptr), NDET_E_INVALID, "%s: scale and shift go together", fn);
+    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
+    NDET_REQUIRE(Cin % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
+    NDET_REQUIRE((((uintptr_t)in | (uintptr_t)w_packed) & 15) == 0, NDET_E_UNSUPPORTED, "%s: in / weights must be 16-byte aligned", fn);
+    for (int a = 0; a < 3; ++a)
+        NDET_REQUIRE(kernel[a] >= 1 && kernel[a] <= 7 && stride[a] >= 1 && stride[a] <= 4 && pad[a] >= 0 && pad[a] < kernel[a], NDET_E_UNSUPPORTED,
+                     "%s: kernel/stride/pad out of range on axis %d", fn, a);
+    Conv3dParams p;
+    p.in = in; p.w = w_packed; p.out = out; p.scale = scale; p.shift = shift; p.res = residual; p.partial = (float*)workspace;
+    p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu; p.transposed = 0;
+    p.kd = kernel[0]; p.kh = kernel[1]; p.kw = kernel[2];
+    p.sd = stride[0]; p.sh = stride[1]; p.sw = stride[2];
+    p.pd = pad[0]; p.ph = pad[1]; p.pw = pad[2];
+    p.OD = (D + 2 * p.pd - p.kd) / p.sd + 1;
+    p.OH = (H + 2 * p.ph - p.kh) / p.sh + 1;
+    p.OW = (W + 2 * p.pw - p.kw) / p.sw + 1;
+    NDET_REQUIRE(p.OD > 0 && p.OH > 0 && p.OW > 0, NDET_E_INVALID, "%s: empty output", fn);
+    NDET_REQUIRE((int64_t)p.OD * p.OH * p.OW < ((int64_t)1 << 31) && (int64_t)D * H * W * Cin < ((int64_t)1 << 40), NDET_E_UNSUPPORTED, "%s: tensor too large", fn);
+    p.M = p.OD * p.OH * p.OW;
+    p.splits = splits < 1 ? 1 : splits;
+    const int iters = p.kd * p.kh * p.kw * (Cin / CBK);
+    NDET_REQUIRE(p.splits <= iters, NDET_E_INVALID, "%s: splits=%d exceeds the %d K steps", fn, p.splits, iters);
+    NDET_REQUIRE(p.splits == 1 || workspace != nullptr, NDET_E_INVALID, "%s: split-K needs a workspace", fn);
+    return conv_launch(p, tile, (hipStream_t)stream, fn);
+}
+
+extern "C" int64_t ndet_conv3d_workspace_bytes(int D, int H, int W, int Cin, int Cout, int ksize, int stride, int splits) {
+    if (splits <= 1) return 0;
+    const int pad = ksize / 2;
+    const int64_t od = (D + 2 * pad - ksize) / stride + 1, oh = (H + 2 * pad - ksize) / stride + 1, ow = (W + 2 * pad - ksize) / stride + 1;
+    return od * oh * ow * (int64_t)Cout * splits * 4;
+}
+
+extern "C" int ndet_conv3d_ndhwc(const float* in, const float* w_packed, float* out, int D, int H, int W, int Cin, int Cout, int ksize,
+                                 int stride, int transposed, const float* scale, const float* shift, const float* residual, int relu,
+                                 int splits, int tile, void* workspace, void* stream) {
+    const char* fn = "ndet_conv3d_ndhwc";
+    if (!transposed) {
+        NDET_REQUIRE((ksize == 3 || ksize == 1) && (stride == 1 || stride == 2), NDET_E_UNSUPPORTED, "%s: kernel %d stride %d unsupported", fn, ksize, stride);
+        const int k[3] = {ksize, ksize, ksize}, s[3] = {stride, stride, stride}, pd[3] = {ksize / 2, ksize / 2, ksize / 2};
+        return ndet_conv_ndhwc(in, w_packed, out, D, H, W, Cin, Cout, k, s, pd, scale, shift, residual, relu, splits, tile, workspace, stream);
+    }
+    NDET_REQUIRE(in && w_packed && out, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
+    NDET_REQUIRE((scale == nullptr) == (shift == nullptr), NDET_E_INVALID, "%s: scale and shift go together", fn);
+    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
+    NDET_REQUIRE(Cin % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
+    NDET_REQUIRE((((uintptr_t)in | (uintptr_t)w_packed) & 15) == 0, NDET_E_UNSUPPORTED, "%s: in / weights must be 16-byte aligned", fn);
+    NDET_REQUIRE(ksize == 2 && stride == 2, NDET_E_UNSUPPORTED, "%s: transposed conv supports kernel 2 stride 2 only", fn);
+    Conv3dParams p;
+    p.in = in; p.w = w_packed; p.out = out; p.scale = scale; p.shift = shift; p.res = residual; p.partial = nullptr;
+    p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu; p.transposed = 1;
+    p.kd = p.kh = p.kw = 2; p.sd = p.sh = p.sw = 2; p.pd = p.ph = p.pw = 0;
+    p.OD = 2 * D; p.OH = 2 * H; p.OW = 2 * W;
+    p.M = D * H * W;
+    p.splits = 1;
+    return conv_launch(p, tile, (hipStream_t)stream, fn);
 }
