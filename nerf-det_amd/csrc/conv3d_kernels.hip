@@ -3,8 +3,8 @@
 //
 //   out[m, co] = epilogue( sum_{tap} sum_{ci} in[nbr(m, tap), ci] * Wp[tap][co][ci] )
 //
-// GEMM view: M = output voxels, N = Cout, K = taps * Cin.  One workgroup = 256 threads = 2 x 2 waves computes a
-// BM x BN tile; K is walked tap-major in steps of BK = 32 input channels.  A rows are gathered on the fly (one
+// GEMM view: M = output voxels, N = Cout, K = taps * Cin.  One workgroup (128 x 128 tile: 8 waves as 4 x 2; 64 x 64
+// tile: 4 waves as 2 x 2) computes a BM x BN tile; K is walked tap-major in steps of BK = 32 input channels.  A rows are gathered on the fly (one
 // 128-byte channel run of the neighbour voxel per (row, tap), zeros outside the grid) -- nothing like the 27x
 // im2col buffer the vendor path materialises.  Both operand tiles sit K-contiguous in LDS ([rows][BK + 4]); a lane
 // reads 4 consecutive k with one ds_read_b128 and feeds them to 4 successive MFMAs (the k permutation is the same
@@ -42,21 +42,23 @@ struct Conv3dParams {
     int M;                // GEMM rows: output voxels (input voxels when transposed)
 };
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_conv3d_igemm(const Conv3dParams p) {
-    constexpr int WM = BM / 2, WN = BN / 2;     // per-wave tile
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void k_conv3d_igemm(const Conv3dParams p) {
+    constexpr int NTHR = 64 * WGM * WGN;        // WGM x WGN waves
+    constexpr int WM = BM / WGM, WN = BN / WGN; // per-wave tile
     constexpr int MT = WM / 16, NT = WN / 16;   // 16x16 MFMA tiles per wave
-    constexpr int AR = BM / 32, BR = BN / 32;   // rows each thread stages per operand
+    constexpr int RPP = NTHR / 8;               // tile rows staged per pass (8 threads cover one 128-byte K run)
+    constexpr int AR = BM / RPP, BR = BN / RPP; // rows each thread stages per operand
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;                       // [2][BM][CLD]
     float* Bs = lds + 2 * BM * CLD;        // [2][BN][CLD]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int chunk = tid & 7;      // which 4-float piece of the 32-float K run
-    const int srow = tid >> 3;      // 0..31
+    const int srow = tid >> 3;      // 0..RPP-1
 
     const int cin_steps = p.Cin / CBK;
     const int taps = p.transposed ? 1 : p.kd * p.kh * p.kw;
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void k_conv3d_igemm(const Conv3dParams p) {
     bool vok[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int m = m0 + srow + 32 * i;
+        const int m = m0 + srow + RPP * i;
         vok[i] = m < p.M;
         const int mm = vok[i] ? m : 0;
         const int ow_ = p.transposed ? p.W : p.OW, oh_ = p.transposed ? p.H : p.OH;
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void k_conv3d_igemm(const Conv3dParams p) {
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            const int co = n0 + srow + 32 * i;
+            const int co = n0 + srow + RPP * i;
             brow[i] = co < p.Cout ? p.w + ((int64_t)tap * p.Cout + co) * p.Cin + chunk * 4 : nullptr;
         }
     };
@@ -139,9 +141,9 @@ __global__ __launch_bounds__(256) void k_conv3d_igemm(const Conv3dParams p) {
         float* a = As + buf * BM * CLD;
         float* b = Bs + buf * BN * CLD;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *reinterpret_cast<float4*>(a + (srow + 32 * i) * CLD + chunk * 4) = ra[i];
+        for (int i = 0; i < AR; ++i) *reinterpret_cast<float4*>(a + (srow + RPP * i) * CLD + chunk * 4) = ra[i];
 #pragma unroll
-        for (int i = 0; i < BR; ++i) *reinterpret_cast<float4*>(b + (srow + 32 * i) * CLD + chunk * 4) = rb[i];
+        for (int i = 0; i < BR; ++i) *reinterpret_cast<float4*>(b + (srow + RPP * i) * CLD + chunk * 4) = rb[i];
     };
 
     if (it_begin < it_end) {
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void k_conv3d_igemm(const Conv3dParams p) {
     };
     if ((p.Cout & 3) == 0) {
         constexpr int V = BN / 4;  // float4 pieces per tile row
-        for (int idx = tid; idx < BM * V; idx += 256) {
+        for (int idx = tid; idx < BM * V; idx += NTHR) {
             const int row = idx / V, c4 = idx % V;
             const int m = m0 + row, co = n0 + c4 * 4;
             if (m >= p.M || co >= p.Cout) continue;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void k_conv3d_igemm(const Conv3dParams p) {
             *reinterpret_cast<float4*>(dst + o) = v;
         }
     } else {  // Cout not a multiple of 4 (the fused head conv, Cout = 25): scalar columns
-        for (int idx = tid; idx < BM * BN; idx += 256) {
+        for (int idx = tid; idx < BM * BN; idx += NTHR) {
             const int row = idx / BN, c = idx % BN;
             const int m = m0 + row, co = n0 + c;
             if (m >= p.M || co >= p.Cout) continue;
@@ -285,26 +287,34 @@ __global__ __launch_bounds__(256) void k_conv3d_splitk_reduce(const float* __res
     out[i] = v;
 }
 
-static int conv_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn) {
-    const int Cout = p.Cout;
+template <int BM, int BN, int WGM, int WGN>
+static int conv_launch_tile(const Conv3dParams& p, hipStream_t st, const char* fn) {
     const int zdim = p.transposed ? 8 : p.splits;
-    const int64_t big_tiles = (int64_t)((p.M + 127) / 128) * ((Cout + 127) / 128);
-    const bool big = tile == 128 || (tile == 0 && big_tiles >= 256 && Cout >= 128);
-    if (big) {
-        dim3 grid((p.M + 127) / 128, (Cout + 127) / 128, zdim);
-        const size_t lds = (size_t)2 * (128 + 128) * CLD * sizeof(float);
-        static bool attr_set = false;  // 72 KiB of dynamic LDS: above the 64 KiB default cap
+    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, zdim);
+    const size_t lds = (size_t)2 * (BM + BN) * CLD * sizeof(float);
+    if (lds > 64 * 1024) {  // above the default dynamic-LDS cap
+        static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_conv3d_igemm<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute((const void*)k_conv3d_igemm<BM, BN, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_conv3d_igemm<128, 128>), grid, dim3(256), lds, st, p);
-    } else {
-        dim3 grid((p.M + 63) / 64, (Cout + 63) / 64, zdim);
-        const size_t lds = (size_t)2 * (64 + 64) * CLD * sizeof(float);
-        hipLaunchKernelGGL((k_conv3d_igemm<64, 64>), grid, dim3(256), lds, st, p);
     }
+    hipLaunchKernelGGL((k_conv3d_igemm<BM, BN, WGM, WGN>), grid, dim3(64 * WGM * WGN), lds, st, p);
+    return NDET_OK;
+}
+
+static int conv_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn) {
+    const int Cout = p.Cout;
+    const int64_t big_tiles = (int64_t)((p.M + 127) / 128) * ((Cout + 127) / 128);
+    if (tile == 0) tile = (big_tiles >= 256 && Cout >= 128) ? 128 : 64;
+    int rc;
+    switch (tile) {
+        case 64: rc = conv_launch_tile<64, 64, 2, 2>(p, st, fn); break;
+        case 128: rc = conv_launch_tile<128, 128, 4, 2>(p, st, fn); break;  // 8 waves (4 x 2): +3 % over 2 x 2 waves, measured
+        default: ndet_set_error("%s: unknown tile %d", fn, tile); return NDET_E_INVALID;
+    }
+    if (rc != NDET_OK) return rc;
     NDET_CHECK_LAUNCH(fn);
     if (!p.transposed && p.splits > 1) {
         const int64_t mn = (int64_t)p.M * Cout;

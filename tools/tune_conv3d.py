@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 from nerfdet_amd.conv3d import conv3d_ndhwc, packed
 
 LAYERS = [  # name, cin, cout, grid(in), k, stride, transposed
+    ("fpn-like 256->256 @(50*60)x80x1 3x3x1?", 256, 256, (60, 80, 50), 3, 1, False),
     ("down0.conv 256->256 @40x40x16", 256, 256, (40, 40, 16), 3, 1, False),
     ("out0 256->128 @40x40x16", 256, 128, (40, 40, 16), 3, 1, False),
     ("down1.conv1 256->512 s2", 256, 512, (40, 40, 16), 3, 2, False),
