@@ -162,6 +162,32 @@ int ndet_conv_ndhwc(const float* in, const float* w_packed, float* out, int D, i
                     const float* shift, const float* residual, int relu, int splits, int tile, void* workspace,
                     void* stream);
 
+/* ---- backward passes (training).  The reference obtains these from autograd over its materialised tensors; each
+ * entry point names the forward statement it differentiates.  Scatter targets must be zero-initialised by the caller;
+ * accumulation uses float atomics (order not fixed). ---- */
+
+/* d(features) of the view mean, mmdet3d/models/detectors/nerfdet.py:164-176: grad_features[v,y,x,:] += grad_mean[n,:] /
+ * (count_n + 1e-8) for every view v that sees voxel n.  grad_mean in `grad_layout`; grad_features_nhwc as features_nhwc. */
+int ndet_backproject_aggregate_bwd(const float* grad_mean, int grad_layout, int n_views, int C, int h, int w,
+                                   int64_t view_pitch, int64_t row_pitch, const float* points, int N,
+                                   const float* projection, float* grad_features_nhwc, void* stream);
+
+/* d(mapped features), d(bias) of ndet_density_features, nerfdet.py:234-253 (the RGB volume carries no gradient). */
+int ndet_density_features_bwd(const float* grad_global_feat, const float* mapped_nhwc, int n_views, int cm, int h, int w,
+                              int64_t mview_pitch, int64_t mrow_pitch, const float* bias, const float* points, int N,
+                              const float* projection, float* grad_mapped_nhwc, float* grad_bias, void* stream);
+
+/* d(mapped features) of ndet_ray_view_stats: F.grid_sample backward (projection.py:127) through the masked statistics of
+ * render_ray.py:83-88.  Sample points and images carry no gradient. */
+int ndet_ray_view_stats_bwd(const float* grad_global_feat, const float* pts, int n_points, const float* KE, int n_views,
+                            float img_h, float img_w, const float* feat_nhwc, int d, int hf, int wf,
+                            int64_t fview_pitch, int64_t frow_pitch, float* grad_feat_nhwc, void* stream);
+
+/* d(raw) of ndet_composite (render_ray.py:196-236) from d(rgb_map) (R,3) and d(depth_map) (R) or NULL.
+ * transparency: the forward's (R,S) output. */
+int ndet_composite_bwd(const float* raw, const float* z_vals, const float* transparency, int R, int S, int white_bkgd,
+                       const float* zminmax, const float* grad_rgb, const float* grad_depth, float* grad_raw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,132 @@
+"""torch.autograd glue for the training path: forward and backward of each op are HIP kernels
+(csrc/volume_kernels.hip, ray_kernels.hip, backward_kernels.hip); the reference gets the same derivatives from
+autograd over its materialised tensors ("autograd must flow through A3-A11 in training")."""
+from __future__ import annotations
+
+from ctypes import c_void_p
+
+import torch
+
+from . import _lib, ops
+from ._lib import NDET_LAYOUT_CN, NDET_LAYOUT_NC, check
+
+
+def _ptr(t):
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(t):
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+class BackprojectMean(torch.autograd.Function):
+    """features (n_v,C,h,w) -> (mean (C,X,Y,Z), count (1,X,Y,Z)); nerfdet.py:164-176."""
+
+    @staticmethod
+    def forward(ctx, features, points, projection, channels_last_out):
+        f = ops.to_channels_last(features.detach())
+        out, cnt = ops.backproject_aggregate(f, points, projection, None, channels_last_out)
+        ctx.save_for_backward(points, projection)
+        ctx.fshape, ctx.fstrides = tuple(f.shape), (f.stride(0), f.stride(2))
+        ctx.mark_non_differentiable(cnt)
+        return out, cnt
+
+    @staticmethod
+    def backward(ctx, g_out, _g_cnt):
+        points, projection = ctx.saved_tensors
+        n_v, c, h, w = ctx.fshape
+        n = g_out[0].numel()
+        g_nc = g_out.permute(1, 2, 3, 0)
+        if g_nc.is_contiguous():
+            g, layout = g_nc, NDET_LAYOUT_NC
+        else:
+            g, layout = g_out.contiguous(), NDET_LAYOUT_CN
+        g = g.float()
+        dfeat = torch.zeros((n_v, h, w, c), dtype=torch.float32, device=g.device)
+        pts = points.float().contiguous()
+        pj = projection.float().contiguous()
+        check(_lib.load().ndet_backproject_aggregate_bwd(_ptr(g), layout, n_v, c, h, w, dfeat.stride(0), dfeat.stride(1), _ptr(pts), n,
+                                                         _ptr(pj), _ptr(dfeat), _stream(g)), "backproject_aggregate_bwd")
+        return dfeat.permute(0, 3, 1, 2), None, None, None
+
+
+class DensityFeatures(torch.autograd.Function):
+    """(mapped (n_v,cm,h,w), bias (cm)) -> global_feat (N, 2*(3+cm)); nerfdet.py:234-253."""
+
+    @staticmethod
+    def forward(ctx, mapped, bias, denorm_images, points, projection, rgb_projection):
+        m = ops.to_channels_last(mapped.detach())
+        out = ops.density_features(m, bias.detach(), denorm_images, points, projection, rgb_projection)
+        ctx.save_for_backward(m, bias.detach(), points, projection)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        m, bias, points, projection = ctx.saved_tensors
+        n_v, cm, h, w = m.shape
+        n = points[0].numel()
+        g = g.float().contiguous()
+        dm = torch.zeros((n_v, h, w, cm), dtype=torch.float32, device=g.device)
+        db = torch.zeros((cm,), dtype=torch.float32, device=g.device)
+        check(_lib.load().ndet_density_features_bwd(_ptr(g), _ptr(m), n_v, cm, h, w, m.stride(0), m.stride(2), _ptr(bias.float().contiguous()),
+                                                    _ptr(points.float().contiguous()), n, _ptr(projection.float().contiguous()), _ptr(dm),
+                                                    _ptr(db), _stream(g)), "density_features_bwd")
+        # m may be a strided channels-last view (cropped map): dm is dense (n_v,h,w,cm) with the same logical shape
+        return dm.permute(0, 3, 1, 2), db, None, None, None, None
+
+
+class RayViewStats(torch.autograd.Function):
+    """featmaps (n_v,d,h,w) -> globalfeat (R,S,2*(3+d)) (+ masks); projection.py:91-151 + render_ray.py:71-93."""
+
+    @staticmethod
+    def forward(ctx, featmaps, xyz, train_imgs, train_cameras):
+        from . import rays
+        f = ops.to_channels_last(featmaps.detach())
+        glob, pm, vc = rays.ray_view_stats(xyz, train_imgs, train_cameras, f)
+        cams = train_cameras.squeeze(0) if train_cameras.dim() == 3 else train_cameras
+        ke, h, w = rays._camera_matrices(cams)
+        ctx.save_for_backward(f, xyz.detach().float().reshape(-1, 3).contiguous(), ke.to(xyz.device))
+        ctx.hw = (h, w)
+        ctx.mark_non_differentiable(pm, vc)
+        return glob, pm, vc
+
+    @staticmethod
+    def backward(ctx, g, _gpm, _gvc):
+        f, pts, ke = ctx.saved_tensors
+        n_v, d, hf, wf = f.shape
+        g = g.float().reshape(pts.shape[0], -1).contiguous()
+        df = torch.zeros((n_v, hf, wf, d), dtype=torch.float32, device=g.device)
+        check(_lib.load().ndet_ray_view_stats_bwd(_ptr(g), _ptr(pts), pts.shape[0], _ptr(ke), n_v, ctx.hw[0], ctx.hw[1], _ptr(f), d, hf, wf,
+                                                  f.stride(0), f.stride(2), _ptr(df), _stream(g)), "ray_view_stats_bwd")
+        return df.permute(0, 3, 1, 2), None, None, None
+
+
+class Composite(torch.autograd.Function):
+    """raw (R,S,4) -> (rgb, depth, weights, alpha, transparency, ray_mask); render_ray.py:196-247.
+    Gradients flow through rgb and depth (what the losses of nerfdet.py:296-321 use)."""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, pixel_mask, white_bkgd):
+        from . import rays
+        out = rays._raw2outputs_impl(raw.detach(), z_vals, pixel_mask, white_bkgd)
+        z = z_vals.detach().float().contiguous()
+        zmm = torch.stack([z.min(), z.max()])
+        ctx.save_for_backward(raw.detach().float().contiguous(), z, out["transparency"], zmm)
+        ctx.white = int(bool(white_bkgd))
+        ctx.mark_non_differentiable(out["weights"], out["alpha"], out["transparency"])
+        mask = out["mask"]
+        if mask is None:
+            mask = torch.empty(0, dtype=torch.bool, device=raw.device)
+        ctx.mark_non_differentiable(mask)
+        return out["rgb"], out["depth"], out["weights"], out["alpha"], out["transparency"], mask
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, *_):
+        raw, z, trans, zmm = ctx.saved_tensors
+        r, s = raw.shape[:2]
+        g_rgb = g_rgb.float().contiguous()
+        g_depth = None if g_depth is None else g_depth.float().contiguous()
+        d_raw = torch.empty_like(raw)
+        check(_lib.load().ndet_composite_bwd(_ptr(raw), _ptr(z), _ptr(trans), r, s, ctx.white, _ptr(zmm), _ptr(g_rgb), _ptr(g_depth), _ptr(d_raw),
+                                             _stream(raw)), "composite_bwd")
+        return d_raw, None, None, None

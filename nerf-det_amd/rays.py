@@ -154,7 +154,17 @@ def sample_along_camera_ray(ray_o, ray_d, depth_range, N_samples, inv_uniform=Fa
 # A11
 # ------------------------------------------------------------------------------------------------------
 def raw2outputs(raw, z_vals, mask, white_bkgd=False):
-    """render_ray.py:196-247 -> OrderedDict(rgb, depth, weights, mask, alpha, z_vals, transparency)."""
+    """render_ray.py:196-247 -> OrderedDict(rgb, depth, weights, mask, alpha, z_vals, transparency).  Differentiable in
+    ``raw`` (through rgb and depth) when it requires grad."""
+    if torch.is_grad_enabled() and raw.requires_grad:
+        from .autograd import Composite
+        rgb, depth, wts, alpha, trans, rmask = Composite.apply(raw, z_vals, mask, white_bkgd)
+        return OrderedDict([("rgb", rgb), ("depth", depth), ("weights", wts), ("mask", None if mask is None else rmask),
+                            ("alpha", alpha), ("z_vals", z_vals), ("transparency", trans)])
+    return _raw2outputs_impl(raw, z_vals, mask, white_bkgd)
+
+
+def _raw2outputs_impl(raw, z_vals, mask, white_bkgd=False):
     if not raw.is_cuda:
         raise RuntimeError("nerfdet_amd.rays: tensors must live on the GPU (no CPU fallback)")
     r, s = raw.shape[:2]
@@ -187,7 +197,11 @@ def render_rays_func(ray_o, ray_d, mean_volume, cov_volume, features_2D, img, aa
     ret = {"outputs_coarse": None, "outputs_fine": None, "gt_rgb": gt_rgb, "gt_depth": gt_depth}
     pts, z_vals = sample_along_camera_ray(ray_o, ray_d, near_far_range, N_samples, inv_uniform=inv_uniform, det=det, t_rand=t_rand)
     cams = _compute_projection(img_meta)
-    globalfeat, pixel_mask, _ = ray_view_stats(pts, img, cams, features_2D)
+    if torch.is_grad_enabled() and features_2D.requires_grad:
+        from .autograd import RayViewStats
+        globalfeat, pixel_mask, _ = RayViewStats.apply(features_2D, pts, img, cams)
+    else:
+        globalfeat, pixel_mask, _ = ray_view_stats(pts, img, cams, features_2D)
     rgb_pts, density_pts = nerf_mlp(pts, ray_d, globalfeat)
     ret["sigma"] = density_pts
     ret["outputs_coarse"] = raw2outputs(torch.cat([rgb_pts, density_pts], dim=-1), z_vals, pixel_mask, white_bkgd=white_bkgd)

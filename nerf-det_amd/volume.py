@@ -51,6 +51,8 @@ def extract_volume(features: Tensor, denorm_images: Tensor, img_meta: dict, n_vo
     if feature_2d is None:
         feature_2d = map_features_2d(feat, lin.weight, lin.bias)
     rgb = denorm_images[:, :, :img_meta["img_shape"][0], :img_meta["img_shape"][1]]
+    if torch.is_grad_enabled() and (feat.requires_grad or lin.weight.requires_grad):
+        return _extract_volume_train(feat, rgb, pts, proj, rgb_proj, lin, nerf_mlp, feature_2d, channels_last_out)
     glob = ops.density_features(feature_2d, lin.bias, rgb, pts, proj, rgb_proj)
     rows = ops.posenc_concat(pts, glob)
     raw_sigma = nerf_mlp.raw_sigma_from_rows(rows)
@@ -58,3 +60,18 @@ def extract_volume(features: Tensor, denorm_images: Tensor, img_meta: dict, n_vo
     volume, count = ops.backproject_aggregate(feat, pts, proj, alpha=alpha, channels_last_out=channels_last_out)
     return dict(volume=volume, valid=count, feature_2d=feature_2d, global_feat=glob, raw_sigma=raw_sigma,
                 alpha=alpha, points=pts, projection=proj, rgb_projection=rgb_proj)
+
+
+def _extract_volume_train(feat, rgb, pts, proj, rgb_proj, lin, nerf_mlp, feature_2d, channels_last_out):
+    """Training form: the same kernels under autograd (nerf_det_amd.autograd); gating stays a differentiable
+    tensor product so that d(alpha) and d(mean) come out separately (nerfdet.py:257-261)."""
+    from .autograd import BackprojectMean, DensityFeatures
+    glob = DensityFeatures.apply(feature_2d, lin.bias, rgb, pts, proj, rgb_proj)
+    rows = torch.cat([ops.posenc_concat(pts, None), glob], dim=1)
+    raw_sigma = nerf_mlp.raw_sigma_from_rows(rows)
+    alpha = 1 - torch.exp(-F.relu(raw_sigma))
+    mean, count = BackprojectMean.apply(feat, pts, proj, channels_last_out)
+    volume = alpha.view(1, *mean.shape[1:]) * mean
+    volume = torch.where((count == 0), torch.zeros_like(volume), volume)
+    return dict(volume=volume, valid=count, feature_2d=feature_2d, global_feat=glob, raw_sigma=raw_sigma, alpha=alpha.reshape(-1),
+                points=pts, projection=proj, rgb_projection=rgb_proj)
