@@ -161,9 +161,9 @@ def test_detector_train_step(device):
     gt_boxes = [DepthInstance3DBoxes(boxes, box_dim=6, with_yaw=False, origin=(0.5, 0.5, 0.5)).to(device)]
     gt_labels = [torch.tensor([2, 7, 11], device=device)]
     params = [p for p in det.parameters() if p.requires_grad]
-    opt = torch.optim.SGD(params, lr=1e-3)
+    opt = torch.optim.SGD(params, lr=2e-5)
     losses = []
-    for it in range(3):
+    for it in range(4):
         rays.rng = np.random.RandomState(234)  # same rays every step so the loss is comparable
         torch.manual_seed(1)
         opt.zero_grad()
