@@ -46,6 +46,20 @@ def k1_algorithmic_bytes(w):
     return w["n_views"] * w["channels"] * hf * wf * 4 + (w["channels"] * 4 + 8) * n
 
 
+def k1_measured_traffic(workload):
+    """HBM-side bytes per K1 launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled as the
+    gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE); None when no profile matches the workload."""
+    path = os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("workload") == workload:
+            return int(d["k1"]["traffic_bytes"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def synth_batch(w, seed):
     """ring cameras, img ~ N(0,1), denorm_images ~ U[0,1), one dummy NeRF target view
     (rays are unused at inference unless render_testing)."""
@@ -232,7 +246,9 @@ def main():
                        "scenes_per_step": world, "parallelism": f"scene replicas x{world} (no data-path collective)"},
             "roofline": {"kernel": "k_backproject_aggregate (fused backproject + view mean/count + alpha gating)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": abytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": k1_measured_traffic(args.workload),
+                         "traffic_source": "profiles/r01_c_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                         "algorithmic_bytes": abytes,
                          "avg_launch_ms": k1_avg_ms, "median_launch_ms": k1_ms[len(k1_ms) // 2]},
             "stages_ms": stages,
             "detections_last_step": int(len(res[0]["scores_3d"])),

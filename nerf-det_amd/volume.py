@@ -34,9 +34,15 @@ def map_features_2d(features: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
     return F.linear(rows, weight, bias).permute(0, 3, 1, 2)
 
 
+def scene_geometry(img_meta: dict, n_voxels, voxel_size, stride: int, device) -> Dict[str, Tensor]:
+    """Per-scene constants of the path (A1 + A2): stride-4 / stride-1 projections and the voxel lattice, on the GPU."""
+    return dict(proj=ops.compute_projection(img_meta, stride, device), rgb_proj=ops.compute_projection(img_meta, 1, device),
+                points=ops.get_points(n_voxels, voxel_size, img_meta["lidar2img"]["origin"], device))
+
+
 def extract_volume(features: Tensor, denorm_images: Tensor, img_meta: dict, n_voxels, voxel_size,
                    mapping: torch.nn.Module, nerf_mlp, stride: int = 4, channels_last_out: bool = True,
-                   feature_2d: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                   feature_2d: Optional[Tensor] = None, geometry: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
     """One scene.  ``features`` (n_v,C,Hf,Wf) FPN level 0 (channels-last preferred), ``denorm_images``
     (n_v,3,H,W).  Returns ``volume`` (C,X,Y,Z) = alpha * mean (zero where unseen), ``valid`` (1,X,Y,Z) int64
     view count, plus ``feature_2d`` (the mapped map, reused by the ray branch) and ``density``."""
@@ -44,9 +50,9 @@ def extract_volume(features: Tensor, denorm_images: Tensor, img_meta: dict, n_vo
     h = img_meta["img_shape"][0] // stride
     w = img_meta["img_shape"][1] // stride
     feat = ops.to_channels_last(features)[:, :, :h, :w]
-    proj = ops.compute_projection(img_meta, stride, dev)
-    rgb_proj = ops.compute_projection(img_meta, 1, dev)
-    pts = ops.get_points(n_voxels, voxel_size, img_meta["lidar2img"]["origin"], dev)
+    if geometry is None:  # hipGraph replay passes static device buffers instead (graphed.py)
+        geometry = scene_geometry(img_meta, n_voxels, voxel_size, stride, dev)
+    proj, rgb_proj, pts = geometry["proj"], geometry["rgb_proj"], geometry["points"]
     lin = mapping[0] if isinstance(mapping, torch.nn.Sequential) else mapping
     if feature_2d is None:
         feature_2d = map_features_2d(feat, lin.weight, lin.bias)

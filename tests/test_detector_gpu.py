@@ -138,3 +138,40 @@ def test_detector_forward_test_vs_oracle_pipeline(device):
     got = res[0]["boxes_3d"].tensor[:, :6].clone()
     got[:, 2] += got[:, 5] * 0.5
     torch.testing.assert_close(got, ref["boxes"], rtol=1e-3, atol=1e-4)
+
+
+def test_graphed_forward_test_equals_eager(device):
+    """hipGraph replay of the static part of forward_test gives the eager result, also for a second scene with
+    different cameras and images fed through the same captured graph."""
+    from nerfdet_amd.config import _wrap
+    from nerfdet_amd.graphed import GraphedForwardTest
+    from nerfdet_amd.presets import nerfdet_cfg
+    from nerfdet_amd.registry import build_detector
+    torch.manual_seed(0)
+    cfg = _wrap(nerfdet_cfg(50, n_voxels=(16, 16, 8), voxel_size=(0.4, 0.4, 0.4)))
+    cfg["test_cfg"]["nms_pre"] = 200
+    det = build_detector(cfg["model"], train_cfg=cfg["train_cfg"], test_cfg=cfg["test_cfg"])
+    with torch.no_grad():
+        det.neck.fpn_convs[0].conv.weight.mul_(1 / 30.0)
+        det.nerf_mlp.mlp.sigma_layer.output_layer.bias.fill_(2.0)
+        det.bbox_head.cls_conv.weight.normal_(0, 0.3)
+        det.bbox_head.cls_conv.bias.fill_(-2.0)
+        det.bbox_head.centerness_conv.weight.normal_(0, 0.1)
+        det.bbox_head.reg_conv.weight.normal_(0, 0.05)
+    det.to(device).eval()
+    graphed = GraphedForwardTest(det)
+    n_v, hw = 6, (64, 96)
+    rays = dict(lightpos=torch.zeros(1, 1, 4, 3, device=device), raydirs=torch.ones(1, 1, 4, 3, device=device),
+                gt_images=torch.zeros(1, 1, 4, 3, device=device), gt_depths=[], nerf_sizes=[torch.tensor([[2, 2, 3]])])
+    for seed, radius in ((0, 2.5), (1, 2.2), (2, 2.8)):
+        g = torch.Generator().manual_seed(seed)
+        meta = O.ring_scene_meta(n_v, hw, radius=radius)
+        img = torch.randn(1, n_v, 3, *hw, generator=g).to(device)
+        dn = torch.rand(1, n_v, 3, *hw, generator=g).to(device)
+        with torch.no_grad():
+            eager = det(img, [dict(meta)], return_loss=False, denorm_images=dn, **rays)
+        got = graphed(img, [dict(meta)], return_loss=False, denorm_images=dn, **rays)
+        assert len(eager[0]["scores_3d"]) > 5
+        assert torch.equal(got[0]["labels_3d"], eager[0]["labels_3d"])
+        assert torch.equal(got[0]["scores_3d"], eager[0]["scores_3d"])
+        assert torch.equal(got[0]["boxes_3d"].tensor, eager[0]["boxes_3d"].tensor)
