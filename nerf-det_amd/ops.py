@@ -120,7 +120,7 @@ def backproject(features: Tensor, points: Tensor, projection: Tensor, depth=None
 # K1: A3 + A4 (+ A6 gating)
 # --------------------------------------------------------------------------------------------
 def backproject_aggregate(features: Tensor, points: Tensor, projection: Tensor, alpha: Optional[Tensor] = None,
-                          channels_last_out: bool = True) -> Tuple[Tensor, Tensor]:
+                          channels_last_out: bool = True, out: Optional[Tuple[Tensor, Tensor]] = None) -> Tuple[Tensor, Tensor]:
     """Fused ``backproject`` + view mean/count of nerfdet.py:164-176 (and, with ``alpha``, the gating of
     nerfdet.py:259-261): returns ``(volume (C,X,Y,Z), count (1,X,Y,Z) int64)``.
 
@@ -138,13 +138,20 @@ def backproject_aggregate(features: Tensor, points: Tensor, projection: Tensor, 
     if alpha is not None:
         alpha = _f32c(alpha).reshape(-1)
         assert alpha.numel() == n
-    count = torch.empty((1, gx, gy, gz), dtype=torch.int64, device=f.device)
-    if channels_last_out:
-        buf = torch.empty((gx, gy, gz, c), dtype=torch.float32, device=f.device)
-        out, layout = buf.permute(3, 0, 1, 2), NDET_LAYOUT_NC
+    if out is not None:  # caller-owned result buffers (static buffers of a hipGraph pipeline)
+        vol, count = out
+        buf = vol.permute(1, 2, 3, 0) if channels_last_out else vol
+        assert buf.is_contiguous() and buf.dtype == torch.float32 and vol.shape == (c, gx, gy, gz)
+        assert count.shape == (1, gx, gy, gz) and count.dtype == torch.int64 and count.is_contiguous()
+        out, layout = vol, (NDET_LAYOUT_NC if channels_last_out else NDET_LAYOUT_CN)
     else:
-        buf = torch.empty((c, gx, gy, gz), dtype=torch.float32, device=f.device)
-        out, layout = buf, NDET_LAYOUT_CN
+        count = torch.empty((1, gx, gy, gz), dtype=torch.int64, device=f.device)
+        if channels_last_out:
+            buf = torch.empty((gx, gy, gz, c), dtype=torch.float32, device=f.device)
+            out, layout = buf.permute(3, 0, 1, 2), NDET_LAYOUT_NC
+        else:
+            buf = torch.empty((c, gx, gy, gz), dtype=torch.float32, device=f.device)
+            out, layout = buf, NDET_LAYOUT_CN
     check(_lib.load().ndet_backproject_aggregate(_ptr(f), n_v, c, h, w, f.stride(0), f.stride(2), _ptr(points), n,
                                                  _ptr(projection), _ptr(alpha), _ptr(buf), layout, _ptr(count),
                                                  _stream(f)), "backproject_aggregate")

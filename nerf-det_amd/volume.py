@@ -40,12 +40,10 @@ def scene_geometry(img_meta: dict, n_voxels, voxel_size, stride: int, device) ->
                 points=ops.get_points(n_voxels, voxel_size, img_meta["lidar2img"]["origin"], device))
 
 
-def extract_volume(features: Tensor, denorm_images: Tensor, img_meta: dict, n_voxels, voxel_size,
-                   mapping: torch.nn.Module, nerf_mlp, stride: int = 4, channels_last_out: bool = True,
-                   feature_2d: Optional[Tensor] = None, geometry: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
-    """One scene.  ``features`` (n_v,C,Hf,Wf) FPN level 0 (channels-last preferred), ``denorm_images``
-    (n_v,3,H,W).  Returns ``volume`` (C,X,Y,Z) = alpha * mean (zero where unseen), ``valid`` (1,X,Y,Z) int64
-    view count, plus ``feature_2d`` (the mapped map, reused by the ray branch) and ``density``."""
+def density_alpha(features: Tensor, denorm_images: Tensor, img_meta: dict, n_voxels, voxel_size, mapping: torch.nn.Module, nerf_mlp,
+                  stride: int = 4, feature_2d: Optional[Tensor] = None, geometry: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
+    """First half of the inference path: mapping GEMM -> K2 -> sigma-MLP -> per-voxel alpha (nerfdet.py:190-197,232-257).
+    Returns everything the aggregation kernel needs (``feat``, ``points``, ``projection``, ``alpha``)."""
     dev = features.device
     h = img_meta["img_shape"][0] // stride
     w = img_meta["img_shape"][1] // stride
@@ -57,15 +55,29 @@ def extract_volume(features: Tensor, denorm_images: Tensor, img_meta: dict, n_vo
     if feature_2d is None:
         feature_2d = map_features_2d(feat, lin.weight, lin.bias)
     rgb = denorm_images[:, :, :img_meta["img_shape"][0], :img_meta["img_shape"][1]]
+    out = dict(feat=feat, feature_2d=feature_2d, points=pts, projection=proj, rgb_projection=rgb_proj, rgb=rgb, lin=lin)
     if torch.is_grad_enabled() and (feat.requires_grad or lin.weight.requires_grad):
-        return _extract_volume_train(feat, rgb, pts, proj, rgb_proj, lin, nerf_mlp, feature_2d, channels_last_out)
+        return out  # training: the caller continues under autograd
     glob = ops.density_features(feature_2d, lin.bias, rgb, pts, proj, rgb_proj)
     rows = ops.posenc_concat(pts, glob)
     raw_sigma = nerf_mlp.raw_sigma_from_rows(rows)
-    alpha = ops.sigma_to_alpha(raw_sigma)
-    volume, count = ops.backproject_aggregate(feat, pts, proj, alpha=alpha, channels_last_out=channels_last_out)
-    return dict(volume=volume, valid=count, feature_2d=feature_2d, global_feat=glob, raw_sigma=raw_sigma,
-                alpha=alpha, points=pts, projection=proj, rgb_projection=rgb_proj)
+    out.update(global_feat=glob, raw_sigma=raw_sigma, alpha=ops.sigma_to_alpha(raw_sigma))
+    return out
+
+
+def extract_volume(features: Tensor, denorm_images: Tensor, img_meta: dict, n_voxels, voxel_size,
+                   mapping: torch.nn.Module, nerf_mlp, stride: int = 4, channels_last_out: bool = True,
+                   feature_2d: Optional[Tensor] = None, geometry: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
+    """One scene.  ``features`` (n_v,C,Hf,Wf) FPN level 0 (channels-last preferred), ``denorm_images``
+    (n_v,3,H,W).  Returns ``volume`` (C,X,Y,Z) = alpha * mean (zero where unseen), ``valid`` (1,X,Y,Z) int64
+    view count, plus ``feature_2d`` (the mapped map, reused by the ray branch) and ``density``."""
+    d = density_alpha(features, denorm_images, img_meta, n_voxels, voxel_size, mapping, nerf_mlp, stride, feature_2d, geometry)
+    if "alpha" not in d:
+        return _extract_volume_train(d["feat"], d["rgb"], d["points"], d["projection"], d["rgb_projection"], d["lin"], nerf_mlp,
+                                     d["feature_2d"], channels_last_out)
+    volume, count = ops.backproject_aggregate(d["feat"], d["points"], d["projection"], alpha=d["alpha"], channels_last_out=channels_last_out)
+    return dict(volume=volume, valid=count, feature_2d=d["feature_2d"], global_feat=d["global_feat"], raw_sigma=d["raw_sigma"],
+                alpha=d["alpha"], points=d["points"], projection=d["projection"], rgb_projection=d["rgb_projection"])
 
 
 def _extract_volume_train(feat, rgb, pts, proj, rgb_proj, lin, nerf_mlp, feature_2d, channels_last_out):
