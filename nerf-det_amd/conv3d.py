@@ -15,8 +15,32 @@ from torch import nn
 
 from . import _lib
 from ._lib import check
+from .conv_tuning import TUNED
 
 _cache = {}
+
+
+def choose_tiling(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 0, transposed: bool = False):
+    """Tile edge (64 / 128) and split-K factor, from sweeps on MI355X (tools/tune_conv3d.py, tools/tune_conv2d.py):
+    128x128 tiles once there are >= 100 of them and the K walk is long enough to amortise the larger epilogue;
+    split K only while every split keeps >= 64 K-steps and the grid stays <= ~1200 (128) / ~2400 (64) workgroups --
+    below that the partial-sum round trip costs more than the extra parallelism buys."""
+    if tile == 0 and splits == 0:
+        hit = TUNED.get((m, cout, k_iters, int(transposed)))
+        if hit is not None:
+            return hit
+    if tile == 0:
+        big = ((m + 127) // 128) * ((cout + 127) // 128)
+        tile = 128 if (big >= 120 and cout >= 128 and k_iters > 4) else 64
+    if splits == 0:
+        if transposed:
+            return tile, 1
+        tiles = ((m + tile - 1) // tile) * ((cout + tile - 1) // tile)
+        cap = 1200 if tile == 128 else 2400
+        splits = 1
+        while splits < 8 and k_iters // (splits + 1) >= 64 and tiles * (splits + 1) <= cap:
+            splits += 1
+    return tile, splits
 
 
 def _ptr(t):
@@ -93,18 +117,10 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
         assert residual.shape == out.shape and residual.is_contiguous()
     lib = _lib.load()
     m = d * h * w if tr else od * oh * ow
-    if splits == 0 or tile == 0:
-        # measured on MI355X (tools/tune_conv3d.py): 128^2 tiles once there are >= 256 of them, else 64^2; split K until
-        # the grid holds ~1200 (128^2) / ~2400 (64^2) workgroups, keeping >= 8 K steps per split
-        if tile == 0:
-            tile = 128 if ((m + 127) // 128) * ((cout + 127) // 128) >= 256 and cout >= 128 else 64
-        if splits == 0:
-            splits = 1
-            if not tr:
-                tiles = ((m + tile - 1) // tile) * ((cout + tile - 1) // tile)
-                iters = k ** 3 * (cin // 32)
-                want = 1200 if tile == 128 else 2400
-                splits = max(1, min(8, (want + tiles - 1) // tiles, iters // 8))
+    if tr:
+        tile, splits = (tile or choose_tiling(m, cout, cin // 32, 0, 0, True)[0]), 1
+    else:
+        tile, splits = choose_tiling(m, cout, k ** 3 * (cin // 32), tile, splits)
     ws = None
     if splits > 1:
         ws = torch.empty((int(lib.ndet_conv3d_workspace_bytes(d, h, w, cin, cout, k, s, splits)),), dtype=torch.uint8, device=x.device)
@@ -128,12 +144,7 @@ def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = No
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous()
     m = n * oh * ow
-    if tile == 0:
-        tile = 128 if ((m + 127) // 128) * ((cout + 127) // 128) >= 256 and cout >= 128 else 64
-    if splits == 0:
-        tiles = ((m + tile - 1) // tile) * ((cout + tile - 1) // tile)
-        iters = kh * kw * (cin // 32)
-        splits = max(1, min(8, ((1200 if tile == 128 else 2400) + tiles - 1) // tiles, iters // 8))
+    tile, splits = choose_tiling(m, cout, kh * kw * (cin // 32), tile, splits)
     ws = torch.empty((m * cout * splits * 4,), dtype=torch.uint8, device=x.device) if splits > 1 else None
     i3 = lambda a, b, c: (ctypes.c_int * 3)(a, b, c)
     st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)

@@ -53,6 +53,8 @@ def main():
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); conv3d_ndhwc(x, pk, relu=1); e1.record(); torch.cuda.synchronize(); auto.append(e0.elapsed_time(e1))
+        m_ = (grid[0]*grid[1]*grid[2]) if tr else od[0]*od[1]*od[2]
+        print("TUNED_JSON", __import__("json").dumps(dict(key=[m_, cout, (1 if tr else k**3) * (cin // 32), int(tr)], tile=best[1], splits=best[2], us=best[0]*1e3, name=name)), flush=True)
         print(f"BEST {name:36s} tile={best[1]} splits={best[2]} {best[0]*1e3:8.1f} us {flops/best[0]/1e9:7.1f} TF | auto {sorted(auto)[2]*1e3:8.1f} us  ({flops/1e9:.1f} GF)", flush=True)
 
 if __name__ == "__main__":
