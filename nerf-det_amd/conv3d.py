@@ -17,9 +17,6 @@ from . import _lib
 from ._lib import check
 from .conv_tuning import TUNED
 
-_cache = {}
-
-
 def choose_tiling(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 0, transposed: bool = False):
     """Tile edge (64 / 128) and split-K factor, from sweeps on MI355X (tools/tune_conv3d.py, tools/tune_conv2d.py):
     128x128 tiles once there are >= 100 of them and the K walk is long enough to amortise the larger epilogue;
@@ -79,9 +76,11 @@ def packed(convs: Sequence[nn.Module], bn: Optional[nn.BatchNorm3d] = None):
     tensors = [t for c in convs for t in (c.weight, c.bias) if t is not None]
     if bn is not None:
         tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
-    key = tuple(id(c) for c in convs) + (id(bn),)
+    # the cache lives ON the first module (dies with it: ids and data pointers of freed modules get reused)
+    store = convs[0].__dict__.setdefault("_ndet_packed", {})
+    key = tuple(id(c) for c in convs[1:]) + (id(bn),)
     stamp = tuple((t.data_ptr(), t._version) for t in tensors)
-    hit = _cache.get(key)
+    hit = store.get(key)
     if hit is not None and hit[0] == stamp:
         return hit[1]
     tr = isinstance(convs[0], nn.ConvTranspose3d)
@@ -95,7 +94,7 @@ def packed(convs: Sequence[nn.Module], bn: Optional[nn.BatchNorm3d] = None):
     c0 = convs[0]
     val = dict(w=w, scale=scale, shift=shift, cout=cout, cin=w.shape[2], ksize=c0.kernel_size[0], stride=c0.stride[0], transposed=tr,
                kernel=tuple(c0.kernel_size), strides=tuple(c0.stride), pads=tuple(c0.padding), ndim=len(c0.kernel_size))
-    _cache[key] = (stamp, val)
+    store[key] = (stamp, val, convs[1:], bn)  # keep the partner modules alive so their ids stay unique
     return val
 
 
