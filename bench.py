@@ -31,6 +31,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4-copy ceiling)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA peak (v_mfma_f32_16x16x4_f32), = fp32 vector peak
 
 WORKLOADS = {
     "cfg2": dict(n_views=50, img_hw=(240, 320), channels=256, n_voxels=(40, 40, 16), voxel_size=(0.16, 0.16, 0.2), depth=50),
@@ -179,6 +180,19 @@ def main():
         return r
     V.ops.backproject_aggregate = timed_k1
 
+    # every launch of the MFMA convolution (the dominant kernel of the step: 3D neck/head + ResNet/FPN bottlenecks)
+    import nerfdet_amd.conv3d as C3
+    conv_events = []
+
+    def conv_hook(flops, thunk):
+        if not record["on"]:
+            return thunk()
+        e0 = ev()
+        r = thunk()
+        conv_events.append((flops, e0, ev()))
+        return r
+    C3.launch_hook = conv_hook
+
     from nerfdet_amd.graphed import GraphedForwardTest
     graphed = GraphedForwardTest(det_gpu)
 
@@ -253,6 +267,9 @@ def main():
     abytes = k1_algorithmic_bytes(w)
     achieved = abytes / (k1_avg_ms * 1e-3) / 1e9
     stages = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in stage_events.items()}
+    conv_ms = [a.elapsed_time(b) for _, a, b in conv_events]
+    conv_flops = sum(f for f, _, _ in conv_events)
+    conv_tflops = conv_flops / (sum(conv_ms) * 1e-3) / 1e12
 
     if rank == 0:
         out = {
@@ -272,7 +289,13 @@ def main():
                                    f"{w['img_hw'][0]}x{w['img_hw'][1]}, {'x'.join(map(str, w['n_voxels']))} voxels, fp32, "
                                    f"1 scene/step/GPU, random-init weights",
                        "scenes_per_step": world, "parallelism": f"scene replicas x{world} (no data-path collective)"},
-            "roofline": {"kernel": "k_backproject_aggregate (fused backproject + view mean/count + alpha gating)",
+            "roofline": {"kernel": "k_conv3d_igemm (fp32-MFMA implicit-GEMM convolution: 3D neck + head, ResNet/FPN bottlenecks; "
+                                   "both tile instantiations, split-K reduce launches included in the event spans)",
+                         "bound": "mfma", "achieved": conv_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": conv_tflops / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "algorithmic_flops_per_step": conv_flops / args.steps, "launches_per_step": len(conv_events) / args.steps,
+                         "avg_launch_ms": sum(conv_ms) / len(conv_ms), "total_ms_per_step": sum(conv_ms) / args.steps},
+            "roofline_projection": {"kernel": "k_backproject_aggregate (fused backproject + view mean/count + alpha gating)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": k1_measured_traffic(args.workload),
                          "traffic_source": "profiles/r01_c_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",

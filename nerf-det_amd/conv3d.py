@@ -17,6 +17,13 @@ from . import _lib
 from ._lib import check
 from .conv_tuning import TUNED
 
+launch_hook = None  # bench.py: callable(flops, thunk) wrapping every MFMA-conv launch (event timing); None = direct
+
+
+def _launch(flops, thunk):
+    return thunk() if launch_hook is None else launch_hook(flops, thunk)
+
+
 def choose_tiling(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 0, transposed: bool = False):
     """Tile edge (64 / 128) and split-K factor, from sweeps on MI355X (tools/tune_conv3d.py, tools/tune_conv2d.py):
     128x128 tiles once there are >= 100 of them and the K walk is long enough to amortise the larger epilogue;
@@ -124,8 +131,9 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
     if splits > 1:
         ws = torch.empty((int(lib.ndet_conv3d_workspace_bytes(d, h, w, cin, cout, k, s, splits)),), dtype=torch.uint8, device=x.device)
     st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-    check(lib.ndet_conv3d_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), d, h, w, cin, cout, k, s, int(tr), _ptr(pk["scale"]), _ptr(pk["shift"]),
-                                _ptr(residual), relu, splits, tile, _ptr(ws), st), "conv3d_ndhwc")
+    flops = 2 * m * cout * cin * (1 if tr else k ** 3) * (8 if tr else 1)
+    _launch(flops, lambda: check(lib.ndet_conv3d_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), d, h, w, cin, cout, k, s, int(tr), _ptr(pk["scale"]),
+                                                       _ptr(pk["shift"]), _ptr(residual), relu, splits, tile, _ptr(ws), st), "conv3d_ndhwc"))
     return out
 
 
@@ -147,8 +155,10 @@ def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = No
     ws = torch.empty((m * cout * splits * 4,), dtype=torch.uint8, device=x.device) if splits > 1 else None
     i3 = lambda a, b, c: (ctypes.c_int * 3)(a, b, c)
     st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-    check(_lib.load().ndet_conv_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), n, h, w, cin, cout, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw),
-                                      _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), relu, splits, tile, _ptr(ws), st), "conv2d_nhwc")
+    lib = _lib.load()
+    _launch(2 * m * cout * cin * kh * kw,
+            lambda: check(lib.ndet_conv_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), n, h, w, cin, cout, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw),
+                                              _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), relu, splits, tile, _ptr(ws), st), "conv2d_nhwc"))
     return out
 
 
