@@ -21,7 +21,11 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define CBK 32          // K step (input channels per step)
-#define CLD (CBK + 4)   // LDS row stride in floats (144 B: 16-B aligned, spreads ds_read_b128 over the banks)
+// LDS row stride in floats.  A lane (row = l & 15, k-group g = l >> 4) reads 16 B at row*LD + 4g; ds_read_b128 is served
+// in 16-lane groups {0-3,12-15,20-27},... over 64 banks.  LD = 40 makes the 16 starts of a group hit 16 distinct
+// 4-bank slots (conflict-free); LD = 36 leaves 2-way conflicts (measured: a third of the LDS cycles) but lets a
+// fourth 64x64 workgroup fit on the CU, which matters more for the small memory-bound layers.
+template <int BM> struct LdsStride { static constexpr int value = (BM >= 128) ? CBK + 8 : CBK + 4; };
 
 struct Conv3dParams {
     const float* in;      // (D, H, W, Cin)
@@ -43,12 +47,13 @@ struct Conv3dParams {
 };
 
 template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN) void k_conv3d_igemm(const Conv3dParams p) {
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void k_conv3d_igemm(const Conv3dParams p) {
     constexpr int NTHR = 64 * WGM * WGN;        // WGM x WGN waves
     constexpr int WM = BM / WGM, WN = BN / WGN; // per-wave tile
     constexpr int MT = WM / 16, NT = WN / 16;   // 16x16 MFMA tiles per wave
     constexpr int RPP = NTHR / 8;               // tile rows staged per pass (8 threads cover one 128-byte K run)
     constexpr int AR = BM / RPP, BR = BN / RPP; // rows each thread stages per operand
+    constexpr int CLD = LdsStride<BM>::value;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;                       // [2][BM][CLD]
     float* Bs = lds + 2 * BM * CLD;        // [2][BN][CLD]
@@ -158,27 +163,30 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv3d_igemm(const Conv3dPar
         if (it + 1 < it_end) load_tile(it + 1);
         const float* a = As + buf * BM * CLD + (wm * WM + frow) * CLD + fk;
         const float* b = Bs + buf * BN * CLD + (wn * WN + frow) * CLD + fk;
+        // all fragment reads of the K step are issued up front (the second half's LDS latency hides behind the first
+        // half's MFMAs; the compiler places counted lgkmcnt waits), then 2 x (MT*NT*4) MFMAs
+        constexpr int KH = CBK / 16;
+        float4 fa[KH][MT], fb[KH][NT];
 #pragma unroll
-        for (int kk = 0; kk < CBK; kk += 16) {
-            float fa[MT][4], fb[NT][4];
+        for (int hk = 0; hk < KH; ++hk) {
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const float4 v = *reinterpret_cast<const float4*>(a + t * 16 * CLD + kk);
-                fa[t][0] = v.x; fa[t][1] = v.y; fa[t][2] = v.z; fa[t][3] = v.w;
-            }
+            for (int t = 0; t < MT; ++t) fa[hk][t] = *reinterpret_cast<const float4*>(a + t * 16 * CLD + hk * 16);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float4 v = *reinterpret_cast<const float4*>(b + t * 16 * CLD + kk);
-                fb[t][0] = v.x; fb[t][1] = v.y; fb[t][2] = v.z; fb[t][3] = v.w;
-            }
+            for (int t = 0; t < NT; ++t) fb[hk][t] = *reinterpret_cast<const float4*>(b + t * 16 * CLD + hk * 16);
+        }
+#pragma unroll
+        for (int hk = 0; hk < KH; ++hk) {
             // j outermost: MT*NT independent accumulators between two dependent MFMAs (40-cycle dependent latency)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int ta = 0; ta < MT; ++ta)
 #pragma unroll
-                    for (int tb = 0; tb < NT; ++tb)
-                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ta][j], fb[tb][j], acc[ta][tb], 0, 0, 0);
+                    for (int tb = 0; tb < NT; ++tb) {
+                        const float av = j == 0 ? fa[hk][ta].x : j == 1 ? fa[hk][ta].y : j == 2 ? fa[hk][ta].z : fa[hk][ta].w;
+                        const float bv = j == 0 ? fb[hk][tb].x : j == 1 ? fb[hk][tb].y : j == 2 ? fb[hk][tb].z : fb[hk][tb].w;
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[ta][tb], 0, 0, 0);
+                    }
         }
         if (it + 1 < it_end) store_tile(buf ^ 1);
         __syncthreads();
@@ -291,7 +299,7 @@ template <int BM, int BN, int WGM, int WGN>
 static int conv_launch_tile(const Conv3dParams& p, hipStream_t st, const char* fn) {
     const int zdim = p.transposed ? 8 : p.splits;
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, zdim);
-    const size_t lds = (size_t)2 * (BM + BN) * CLD * sizeof(float);
+    const size_t lds = (size_t)2 * (BM + BN) * LdsStride<BM>::value * sizeof(float);
     if (lds > 64 * 1024) {  // above the default dynamic-LDS cap
         static bool attr_set = false;
         if (!attr_set) {
