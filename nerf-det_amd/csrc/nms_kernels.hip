@@ -97,8 +97,12 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long* __re
     unsigned long long removed = 0ull;  // lane w holds bits [64w, 64w+64)
     constexpr int PF = 8;
     unsigned long long row[PF];
+    int ord[PF];  // original index of candidate i, prefetched with its row (a load inside the serial chain costs ~0.5 us per pick)
 #pragma unroll
-    for (int k = 0; k < PF; ++k) row[k] = (k < n && lane < words && lane >= k / 64) ? mask[(int64_t)k * words + lane] : 0ull;
+    for (int k = 0; k < PF; ++k) {
+        row[k] = (k < n && lane < words && lane >= k / 64) ? mask[(int64_t)k * words + lane] : 0ull;
+        ord[k] = k < n ? order[k] : 0;
+    }
     int kept = 0;
     for (int i0 = 0; i0 < n; i0 += PF) {
 #pragma unroll
@@ -111,13 +115,14 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long* __re
                 const unsigned wsel = (unsigned)__builtin_amdgcn_readlane((int)half, i >> 6);
                 const bool gone = (wsel >> (i & 31)) & 1u;
                 if (!gone) {
-                    if (lane == 0) keep[kept] = (int64_t)order[i];
+                    if (lane == 0) keep[kept] = (int64_t)ord[k];
                     ++kept;
                     removed |= row[k];
                 }
             }
             const int nx = i + PF;  // refill this slot; words left of the diagonal were never written -> skip them
             row[k] = (nx < n && lane < words && lane >= nx / 64) ? mask[(int64_t)nx * words + lane] : 0ull;
+            ord[k] = nx < n ? order[nx] : 0;
         }
     }
     if (lane == 0) *n_keep = kept;
