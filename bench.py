@@ -224,10 +224,9 @@ def main():
             e2 = ev()
             x3 = det_gpu.neck_3d(out["volume"].unsqueeze(0))
             e3 = ev()
-            outs = det_gpu.bbox_head(x3)
             from nerfdet_amd.boxes import DepthInstance3DBoxes, bbox3d2result
             batch["img_metas"][0].setdefault("box_type_3d", DepthInstance3DBoxes)
-            boxes = det_gpu.bbox_head.get_bboxes(*outs, out["valid"].unsqueeze(0).float(), batch["img_metas"])
+            boxes = det_gpu.bbox_head.simple_test_fused(x3, out["valid"].unsqueeze(0).float(), batch["img_metas"])
             res = [bbox3d2result(*bx) for bx in boxes]
             e4 = ev()
             for name, a, c in (("backbone_fpn", e0, e1), ("volumetric_hot_path", e1, e2), ("neck3d", e2, e3), ("head_nms", e3, e4)):

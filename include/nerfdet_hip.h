@@ -104,6 +104,15 @@ int64_t ndet_nms_workspace_bytes(int n);
 int ndet_aligned_3d_nms(const float* boxes, const float* scores, const int64_t* classes, int n, float thresh,
                         int64_t* keep, int64_t* n_keep, void* workspace, void* stream);
 
+/* A14 decode. One pass per head level over the fused head convolution output raw (N, 7 + n_cls) =
+ * [centerness logit | 6 reg | n_cls class logits]: best class score = max_k sigmoid(cls_k)*sigmoid(centerness)*valid, its label,
+ * and the decoded box (x1,y1,z1,x2,y2,z2) = voxel corner -/+ exp(scale*reg).  Replaces the elementwise chain of
+ * mmdet3d/models/dense_heads/imvoxel_head_v2.py:262-271 + :447 + :547-555 (top-k, thresholding and NMS follow).
+ * valid (N) uint8; scale: DEVICE pointer to the level's learnable scalar; voxel_size_host already multiplied by 2^level. */
+int ndet_head_decode(const float* raw, int n_cls, const uint8_t* valid, const float* scale, int nx, int ny, int nz,
+                     const float* voxel_size_host, const float* origin_host, float* best, int64_t* label, float* boxes,
+                     void* stream);
+
 /* A9. Samples along rays. Replaces sample_along_camera_ray(), mmdet3d/models/model_utils/render_ray.py:145-189
  * (inv_uniform=False).  ray_o, ray_d (R,3); t_rand NULL (det=True) or (R,S) uniforms in [0,1) -- the stream the
  * reference draws with torch.rand_like, injectable for parity.  Outputs pts (R,S,3), z_vals (R,S). */
@@ -155,12 +164,14 @@ int ndet_conv3d_ndhwc(const float* in, const float* w_packed, float* out, int D,
 /* Generic form of the same kernel: per-axis kernel / stride / zero-pad (3 ints each, HOST memory, order D,H,W).
  * A batch of 2D feature maps (N,H,W,C) is the case D = N, kernel[0] = 1, pad[0] = 0 -- used for the ResNet/FPN convolutions
  * (conv + eval-BatchNorm + ReLU + residual in one pass; third-party mmdet ResNet/FPN, SURVEY.md appendix C, called at
- * mmdet3d/models/detectors/nerfdet.py:140-142).  w_packed (kd*kh*kw, Cout, Cin).  Other arguments as ndet_conv3d_ndhwc;
+ * mmdet3d/models/detectors/nerfdet.py:140-142).  w_packed (kd*kh*kw, Cout, Cin).  residual_up2 != 0: `residual` is the
+ * coarser (OD, ceil(OH/2), ceil(OW/2), Cout) map and is added at (d, h>>1, w>>1) -- FPN's nearest-x2 top-down add fused
+ * into the lateral convolution (not combinable with split-K).  Other arguments as ndet_conv3d_ndhwc;
  * split-K workspace = splits * OD*OH*OW*Cout * 4 bytes. */
 int ndet_conv_ndhwc(const float* in, const float* w_packed, float* out, int D, int H, int W, int Cin, int Cout,
                     const int* kernel_host, const int* stride_host, const int* pad_host, const float* scale,
-                    const float* shift, const float* residual, int relu, int splits, int tile, void* workspace,
-                    void* stream);
+                    const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
+                    void* workspace, void* stream);
 
 /* ---- backward passes (training).  The reference obtains these from autograd over its materialised tensors; each
  * entry point names the forward statement it differentiates.  Scatter targets must be zero-initialised by the caller;

@@ -33,6 +33,7 @@ SIGNATURES = {
     "ndet_posenc_concat": ([_P, _P, c_int, c_int, _P, _P], c_int),
     "ndet_nms_workspace_bytes": ([c_int], c_int64),
     "ndet_aligned_3d_nms": ([_P, _P, _P, c_int, c_float, _P, _P, _P, _P], c_int),
+    "ndet_head_decode": ([_P, c_int, _P, _P, c_int, c_int, c_int, _F3, _F3, _P, _P, _P, _P], c_int),
     "ndet_sample_along_rays": ([_P, _P, c_int, c_int, c_float, c_float, _P, _P, _P, _P], c_int),
     "ndet_ray_view_stats": ([_P, c_int, _P, c_int, c_float, c_float, _P, c_int, c_int, c_int64, c_int64, c_int64,
                              _P, c_int, c_int, c_int, c_int64, c_int64, _P, _P, _P, _P], c_int),
@@ -45,7 +46,7 @@ SIGNATURES = {
     "ndet_composite_bwd": ([_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P], c_int),
     "ndet_conv3d_workspace_bytes": ([c_int] * 8, c_int64),
     "ndet_conv_ndhwc": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
-                         ctypes.POINTER(c_int), _P, _P, _P, c_int, c_int, c_int, _P, _P], c_int),
+                         ctypes.POINTER(c_int), _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_conv3d_ndhwc": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_int,
                            _P, _P], c_int),
 }

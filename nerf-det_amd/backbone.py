@@ -180,9 +180,21 @@ class FPN(nn.Module):
 
     def forward(self, inputs):
         hip = self.use_hip and inputs[0].is_cuda and inputs[0].dtype == torch.float32 and not torch.is_grad_enabled()
-        conv = (lambda m, x: conv2d_nhwc(_nhwc(x), packed([m.conv])).permute(0, 3, 1, 2)) if hip else (lambda m, x: m(x))
-        lat = [conv(l, x) for l, x in zip(self.lateral_convs, inputs)]
+        if hip and all(tuple(inputs[i].shape[2:]) == tuple((s + 1) // 2 for s in inputs[i - 1].shape[2:]) for i in range(1, len(inputs))):
+            return self.forward_hip(inputs)
+        lat = [l(x) for l, x in zip(self.lateral_convs, inputs)]
         for i in range(len(lat) - 1, 0, -1):
             lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest")
         act = range(len(lat)) if self.active_outs is None else self.active_outs
-        return tuple(conv(self.fpn_convs[i], lat[i]) if i in act else None for i in range(len(lat)))
+        return tuple(self.fpn_convs[i](lat[i]) if i in act else None for i in range(len(lat)))
+
+    def forward_hip(self, inputs):
+        """Coarse to fine: each lateral 1x1 conv adds the (nearest x2 upsampled) coarser lateral in its epilogue, so the
+        top-down pathway costs no extra pass; then the 3x3 output convs of the active levels."""
+        n = len(inputs)
+        lat = [None] * n
+        for i in range(n - 1, -1, -1):
+            lat[i] = conv2d_nhwc(_nhwc(inputs[i]), packed([self.lateral_convs[i].conv]), residual=lat[i + 1] if i + 1 < n else None,
+                                 residual_up2=i + 1 < n)
+        act = range(n) if self.active_outs is None else self.active_outs
+        return tuple(conv2d_nhwc(lat[i], packed([self.fpn_convs[i].conv])).permute(0, 3, 1, 2) if i in act else None for i in range(n))

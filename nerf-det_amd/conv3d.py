@@ -137,7 +137,8 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
     return out
 
 
-def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = None, relu: int = 0, splits: int = 0, tile: int = 0):
+def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = None, relu: int = 0, splits: int = 0, tile: int = 0,
+                residual_up2: bool = False):
     """Batch of 2D maps, x (N,H,W,Cin) contiguous fp32 -> (N,OH,OW,Cout): Conv2d (+ eval BatchNorm2d / bias) + ReLU +
     residual in one pass of the MFMA kernel (the batch is the kernel's depth axis with extent-1 taps)."""
     if not x.is_cuda:
@@ -149,7 +150,10 @@ def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = No
     oh, ow = (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
     out = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
     if residual is not None:
-        assert residual.shape == out.shape and residual.is_contiguous()
+        want = (n, (oh + 1) // 2, (ow + 1) // 2, cout) if residual_up2 else tuple(out.shape)
+        assert tuple(residual.shape) == want and residual.is_contiguous(), (tuple(residual.shape), want)
+        if residual_up2:
+            splits = 1
     m = n * oh * ow
     tile, splits = choose_tiling(m, cout, kh * kw * (cin // 32), tile, splits)
     ws = torch.empty((m * cout * splits * 4,), dtype=torch.uint8, device=x.device) if splits > 1 else None
@@ -158,7 +162,8 @@ def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = No
     lib = _lib.load()
     _launch(2 * m * cout * cin * kh * kw,
             lambda: check(lib.ndet_conv_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), n, h, w, cin, cout, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw),
-                                              _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), relu, splits, tile, _ptr(ws), st), "conv2d_nhwc"))
+                                              _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), int(residual_up2), relu, splits, tile, _ptr(ws), st),
+                          "conv2d_nhwc"))
     return out
 
 

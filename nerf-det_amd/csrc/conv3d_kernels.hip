@@ -44,6 +44,8 @@ struct Conv3dParams {
     int transposed;       // 1: ConvTranspose3d k=2 s=2 (blockIdx.z = tap)
     int splits;           // split-K factor (blockIdx.z = split) when !transposed
     int M;                // GEMM rows: output voxels (input voxels when transposed)
+    int res_up2;          // 1: residual is a (OD, ceil(OH/2), ceil(OW/2), Cout) map read at (d, h>>1, w>>1): nearest x2 upsample-add
+    int RH, RW;           //    its H and W
 };
 
 template <int BM, int BN, int WGM, int WGN>
@@ -211,6 +213,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void k_co
 
     const bool raw = (!p.transposed && p.splits > 1);
     float* dst = raw ? p.partial + (int64_t)blockIdx.z * p.M * p.Cout : p.out;
+    auto res_row = [&](int m, int64_t orow) -> int64_t {
+        if (!p.res_up2) return orow;
+        const int ow = m % p.OW, oh = (m / p.OW) % p.OH, od = m / (p.OW * p.OH);
+        return ((int64_t)od * p.RH + (oh >> 1)) * p.RW + (ow >> 1);
+    };
     auto out_row = [&](int m) -> int64_t {
         if (!p.transposed) return m;
         const int iw = m % p.W, ih = (m / p.W) % p.H, id = m / (p.W * p.H);
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void k_co
                 }
                 if (p.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (p.res) {
-                    const float4 rr = *reinterpret_cast<const float4*>(p.res + o);
+                    const float4 rr = *reinterpret_cast<const float4*>(p.res + res_row(m, out_row(m)) * p.Cout + co);
                     v.x = v.x + rr.x; v.y = v.y + rr.y; v.z = v.z + rr.z; v.w = v.w + rr.w;
                 }
                 if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void k_co
             if (!raw) {
                 if (p.scale) v = v * p.scale[co] + p.shift[co];
                 if (p.relu == 2) v = fmaxf(v, 0.0f);
-                if (p.res) v = v + p.res[o];
+                if (p.res) v = v + p.res[res_row(m, out_row(m)) * p.Cout + co];
                 if (p.relu == 1) v = fmaxf(v, 0.0f);
             }
             dst[o] = v;
@@ -336,7 +343,7 @@ static int conv_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn
 
 extern "C" int ndet_conv_ndhwc(const float* in, const float* w_packed, float* out, int D, int H, int W, int Cin, int Cout,
                                const int* kernel, const int* stride, const int* pad, const float* scale, const float* shift,
-                               const float* residual, int relu, int splits, int tile, void* workspace, void* stream) {
+                               const float* residual, int residual_up2, int relu, int splits, int tile, void* workspace, void* stream) {
     const char* fn = "ndet_conv_ndhwc";
     NDET_REQUIRE(in && w_packed && out && kernel && stride && pad, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
@@ -360,6 +367,9 @@ extern "C" int ndet_conv_ndhwc(const float* in, const float* w_packed, float* ou
     NDET_REQUIRE((int64_t)p.OD * p.OH * p.OW < ((int64_t)1 << 31) && (int64_t)D * H * W * Cin < ((int64_t)1 << 40), NDET_E_UNSUPPORTED, "%s: tensor too large", fn);
     p.M = p.OD * p.OH * p.OW;
     p.splits = splits < 1 ? 1 : splits;
+    p.res_up2 = (residual && residual_up2) ? 1 : 0;
+    p.RH = (p.OH + 1) / 2; p.RW = (p.OW + 1) / 2;
+    NDET_REQUIRE(!(p.res_up2 && p.splits > 1), NDET_E_UNSUPPORTED, "%s: upsampled residual cannot be combined with split-K", fn);
     const int iters = p.kd * p.kh * p.kw * (Cin / CBK);
     NDET_REQUIRE(p.splits <= iters, NDET_E_INVALID, "%s: splits=%d exceeds the %d K steps", fn, p.splits, iters);
     NDET_REQUIRE(p.splits == 1 || workspace != nullptr, NDET_E_INVALID, "%s: split-K needs a workspace", fn);
@@ -380,7 +390,7 @@ extern "C" int ndet_conv3d_ndhwc(const float* in, const float* w_packed, float* 
     if (!transposed) {
         NDET_REQUIRE((ksize == 3 || ksize == 1) && (stride == 1 || stride == 2), NDET_E_UNSUPPORTED, "%s: kernel %d stride %d unsupported", fn, ksize, stride);
         const int k[3] = {ksize, ksize, ksize}, s[3] = {stride, stride, stride}, pd[3] = {ksize / 2, ksize / 2, ksize / 2};
-        return ndet_conv_ndhwc(in, w_packed, out, D, H, W, Cin, Cout, k, s, pd, scale, shift, residual, relu, splits, tile, workspace, stream);
+        return ndet_conv_ndhwc(in, w_packed, out, D, H, W, Cin, Cout, k, s, pd, scale, shift, residual, 0, relu, splits, tile, workspace, stream);
     }
     NDET_REQUIRE(in && w_packed && out, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
@@ -396,5 +406,6 @@ extern "C" int ndet_conv3d_ndhwc(const float* in, const float* w_packed, float* 
     p.OD = 2 * D; p.OH = 2 * H; p.OW = 2 * W;
     p.M = D * H * W;
     p.splits = 1;
+    p.res_up2 = 0; p.RH = p.RW = 0;
     return conv_launch(p, tile, (hipStream_t)stream, fn);
 }

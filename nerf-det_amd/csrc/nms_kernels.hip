@@ -155,3 +155,54 @@ extern "C" int ndet_aligned_3d_nms(const float* boxes, const float* scores, cons
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// A14 decode: one pass over a head level's fused conv output (N, 1 + n_reg + n_cls) = [centerness | reg | cls logits]:
+//   score_k = sigmoid(cls_k) * sigmoid(centerness) * valid;  best = max_k, label = first argmax          (imvoxel_head_v2.py:266-271)
+//   d = exp(scale * reg);  box = (p - d0, p - d2, p - d4, p + d1, p + d3, p + d5) at the voxel lower corner p   (:447,:547-555)
+// with p = idx * voxel_size + new_origin computed as get_points does.  Replaces ~25 elementwise launches per level.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_head_decode(const float* __restrict__ raw, int n_cls, const uint8_t* __restrict__ valid,
+                                                     const float* __restrict__ scale, int nx, int ny, int nz, float vx, float vy, float vz,
+                                                     float ox, float oy, float oz, float* __restrict__ best, int64_t* __restrict__ label,
+                                                     float* __restrict__ boxes) {
+    const int N = nx * ny * nz;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int stride = 7 + n_cls;
+    const float* r = raw + (int64_t)n * stride;
+    const float ctr = 1.0f / (1.0f + expf(-r[0]));
+    const float v = valid[n] ? 1.0f : 0.0f;
+    float bs = -1.0f;
+    int bl = 0;
+    for (int k = 0; k < n_cls; ++k) {
+        const float sc = ((1.0f / (1.0f + expf(-r[7 + k]))) * ctr) * v;
+        if (sc > bs) { bs = sc; bl = k; }
+    }
+    best[n] = bs;
+    label[n] = bl;
+    const int iz = n % nz, iy = (n / nz) % ny, ix = n / (nz * ny);
+    const float px = (float)ix * vx + ox, py = (float)iy * vy + oy, pz = (float)iz * vz + oz;
+    const float s = scale[0];
+    float d[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d[k] = expf(r[1 + k] * s);
+    float* b = boxes + (int64_t)n * 6;
+    b[0] = px - d[0]; b[1] = py - d[2]; b[2] = pz - d[4];
+    b[3] = px + d[1]; b[4] = py + d[3]; b[5] = pz + d[5];
+}
+
+extern "C" int ndet_head_decode(const float* raw, int n_cls, const uint8_t* valid, const float* scale, int nx, int ny, int nz,
+                                const float* voxel_size_host, const float* origin_host, float* best, int64_t* label, float* boxes, void* stream) {
+    const char* fn = "ndet_head_decode";
+    NDET_REQUIRE(raw && valid && scale && voxel_size_host && origin_host && best && label && boxes, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(nx > 0 && ny > 0 && nz > 0 && n_cls > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
+    volatile float hx = (float)nx / 2.0f, hy = (float)ny / 2.0f, hz = (float)nz / 2.0f;
+    volatile float mx = hx * voxel_size_host[0], my = hy * voxel_size_host[1], mz = hz * voxel_size_host[2];
+    const float ox = origin_host[0] - mx, oy = origin_host[1] - my, oz = origin_host[2] - mz;
+    const int N = nx * ny * nz;
+    hipLaunchKernelGGL(k_head_decode, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, raw, n_cls, valid, scale, nx, ny, nz,
+                       voxel_size_host[0], voxel_size_host[1], voxel_size_host[2], ox, oy, oz, best, label, boxes);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}

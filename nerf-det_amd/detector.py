@@ -175,10 +175,12 @@ class nerfdet(BaseDetector):
 
     def simple_test(self, img, img_metas, depth=None, ray_batch=None, evaluate_nerf=False):
         x, valids, _, _, _ = self.extract_feat(img, img_metas, "test", depth, ray_batch)
-        outs = self.bbox_head(x)
         for m in img_metas:
             m.setdefault("box_type_3d", DepthInstance3DBoxes)
-        bbox_list = self.bbox_head.get_bboxes(*outs, valids.float(), img_metas)
+        if hasattr(self.bbox_head, "can_fuse") and self.bbox_head.can_fuse(x) and len(img_metas) == 1:
+            bbox_list = self.bbox_head.simple_test_fused(x, valids.float(), img_metas)
+        else:
+            bbox_list = self.bbox_head.get_bboxes(*self.bbox_head(x), valids.float(), img_metas)
         return [bbox3d2result(b, s, l) for b, s, l in bbox_list]
 
     def aug_test(self, imgs, img_metas):

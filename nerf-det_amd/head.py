@@ -147,6 +147,54 @@ class ScanNetImVoxelHeadV2(nn.Module):
         b = img_meta["box_type_3d"](b, origin=(0.5, 0.5, 0.5), box_dim=6, with_yaw=False)
         return b, scores[ids], labels[ids]
 
+    # ---- fused inference (HIP decode) ---------------------------------------------------------
+    def can_fuse(self, x) -> bool:
+        return (x[0].is_cuda and not self.training and not torch.is_grad_enabled() and x[0].shape[1] % 32 == 0
+                and x[0].shape[0] == 1 and self.reg_conv.out_channels == 6)
+
+    def simple_test_fused(self, x, valid, img_metas):
+        """forward + get_bboxes for one scene with the per-level elementwise chain in one kernel
+        (csrc/nms_kernels.hip::k_head_decode): fused head conv -> decode (best score, label, box per voxel) ->
+        top-``nms_pre`` per level -> threshold -> greedy NMS.  Same candidates in the same order as
+        :meth:`get_bboxes` (imvoxel_head_v2.py:216-285,528-545)."""
+        import numpy as np
+        from ctypes import c_void_p
+        from . import _lib
+        from ._lib import check, float3
+        lib = _lib.load()
+        meta = img_metas[0]
+        pk = packed([self.centerness_conv, self.reg_conv, self.cls_conv])
+        dev = x[0].device
+        st = c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        bests, labels, boxes = [], [], []
+        for i, (f, sc) in enumerate(zip(x, self.scales)):
+            raw = conv3d_ndhwc(to_ndhwc(f[0].float()), pk)  # (X,Y,Z,25)
+            gx, gy, gz = raw.shape[:3]
+            n = gx * gy * gz
+            v = nn.functional.interpolate(valid, size=(gx, gy, gz), mode="trilinear").round().bool().reshape(-1).contiguous()
+            best = torch.empty((n,), dtype=torch.float32, device=dev)
+            lab = torch.empty((n,), dtype=torch.int64, device=dev)
+            box = torch.empty((n, 6), dtype=torch.float32, device=dev)
+            vs = (torch.tensor(self.voxel_size) * (2 ** i)).tolist()
+            check(lib.ndet_head_decode(c_void_p(raw.data_ptr()), self.n_classes, c_void_p(v.data_ptr()), c_void_p(sc.scale.data_ptr()),
+                                       gx, gy, gz, float3(np.float32(vs)), float3(np.float32(np.asarray(meta["lidar2img"]["origin"]))),
+                                       c_void_p(best.data_ptr()), c_void_p(lab.data_ptr()), c_void_p(box.data_ptr()), st), "head_decode")
+            if n > self.test_cfg.nms_pre > 0:
+                best, ids = best.topk(self.test_cfg.nms_pre)
+                lab, box = lab[ids], box[ids]
+            bests.append(best)
+            labels.append(lab)
+            boxes.append(box)
+        best, lab, box = torch.cat(bests), torch.cat(labels), torch.cat(boxes)
+        keep = best > self.test_cfg.score_thr
+        best, lab, box = best[keep], lab[keep], box[keep]
+        ids = aligned_3d_nms(box, best, lab, self.test_cfg.iou_thr)
+        b = box[ids]
+        b = torch.stack(((b[:, 0] + b[:, 3]) / 2.0, (b[:, 1] + b[:, 4]) / 2.0, (b[:, 2] + b[:, 5]) / 2.0,
+                         b[:, 3] - b[:, 0], b[:, 4] - b[:, 1], b[:, 5] - b[:, 2]), dim=1)
+        b = meta["box_type_3d"](b, origin=(0.5, 0.5, 0.5), box_dim=6, with_yaw=False)
+        return [(b, best[ids], lab[ids])]
+
     # ---- training (A16) --------------------------------------------------------------------
     def loss(self, centernesses, bbox_preds, cls_scores, valid, img_metas, gt_bboxes, gt_labels):
         assert len(centernesses[0]) == len(valid) == len(img_metas) == len(gt_bboxes) == len(gt_labels)

@@ -175,3 +175,30 @@ def test_graphed_forward_test_equals_eager(device):
         assert torch.equal(got[0]["labels_3d"], eager[0]["labels_3d"])
         assert torch.equal(got[0]["scores_3d"], eager[0]["scores_3d"])
         assert torch.equal(got[0]["boxes_3d"].tensor, eager[0]["boxes_3d"].tensor)
+
+
+def test_fused_head_decode_equals_standard_get_bboxes(device):
+    """simple_test_fused (one decode kernel per level) == forward + get_bboxes (the reference's op chain) on the GPU."""
+    from nerfdet_amd.boxes import DepthInstance3DBoxes
+    from nerfdet_amd.config import ConfigDict
+    from nerfdet_amd.head import ScanNetImVoxelHeadV2
+    torch.manual_seed(3)
+    head = ScanNetImVoxelHeadV2(n_classes=18, n_channels=128, n_reg_outs=6, n_scales=3, limit=27, centerness_topk=18,
+                                test_cfg=ConfigDict(nms_pre=300, iou_thr=0.25, score_thr=0.01))
+    head.voxel_size = (0.16, 0.16, 0.2)
+    with torch.no_grad():
+        head.cls_conv.weight.normal_(0, 0.05); head.cls_conv.bias.normal_(-2, 0.3)
+        head.reg_conv.weight.normal_(0, 0.02); head.centerness_conv.weight.normal_(0, 0.05)
+        for i, sc in enumerate(head.scales):
+            sc.scale.fill_(1.0 + 0.3 * i)
+    head.to(device).eval()
+    feats = [torch.randn(1, 128, 24 // 2 ** i, 24 // 2 ** i, 8 // 2 ** i, device=device) for i in range(3)]
+    valid = ((torch.rand(1, 1, 24, 24, 8, device=device) < 0.7).float() * torch.randint(1, 6, (1, 1, 24, 24, 8), device=device).float())
+    meta = dict(lidar2img=dict(origin=np.array([0.0, 0.0, 0.5], dtype=np.float32)), box_type_3d=DepthInstance3DBoxes)
+    with torch.no_grad():
+        (b0, s0, l0), = head.get_bboxes(*head(feats), valid, [meta])
+        (b1, s1, l1), = head.simple_test_fused(feats, valid, [meta])
+    assert len(s0) > 30
+    assert torch.equal(l0, l1)
+    torch.testing.assert_close(s1, s0, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(b1.tensor, b0.tensor, rtol=1e-5, atol=1e-5)
