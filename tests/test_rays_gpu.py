@@ -165,3 +165,29 @@ def test_ray_stats_training_size_vs_oracle_and_properties(device):
                                              feat[perm].to(device).contiguous(memory_format=torch.channels_last))
     assert torch.equal(vc_p, vc) and torch.equal(pm_p, pm)
     torch.testing.assert_close(glob_p, glob, rtol=0, atol=ATOL)
+
+
+def test_render_testing_chunks_equal_one_pass(device):
+    """render_rays(render_testing=True) (render_ray.py:452-517): every ray of the target views, chunks of N_rand,
+    deterministic sampling -- equals one render_rays_func over all rays, reshaped to (views, H, W, .)."""
+    from nerfdet_amd import rays
+    g = load_golden("rays_small_s0")
+    mlp = _mlp(g, device)
+    meta = golden_meta(g)
+    t_views, hh, ww = 2, 6, 7
+    gen = torch.Generator().manual_seed(4)
+    ang = torch.rand(1, t_views, hh * ww, generator=gen) * 2 * np.pi
+    ray_o = torch.stack([2.0 * torch.cos(ang), 2.0 * torch.sin(ang), 1.0 + 0 * ang], -1).to(device)
+    ray_d = (-ray_o.cpu() / ray_o.cpu().norm(dim=-1, keepdim=True) + 0.3 * torch.randn(1, t_views, hh * ww, 3, generator=gen)).to(device)
+    rb = dict(ray_o=ray_o, ray_d=ray_d, gt_rgb=torch.rand(1, t_views, hh * ww, 3, generator=gen).to(device),
+              gt_depth=torch.rand(1, t_views, hh, ww, generator=gen).to(device), nerf_sizes=[torch.tensor([[hh, ww, 3]])])
+    f2d, img, s = g["features_2d"].to(device), g["img"].to(device), int(g["n_samples"])
+    with torch.no_grad():
+        ret = rays.render_rays(rb, None, None, f2d, img, None, [0.2, 8.0], s, 16, mlp, meta, None, "image", is_train=False,
+                               render_testing=True)
+        one = rays.render_rays_func(ray_o.view(-1, 3), ray_d.view(-1, 3), None, None, f2d, img, None, [0.2, 8.0], s, 16, mlp, meta,
+                                    None, "image", det=True)
+    assert ret["outputs_coarse"]["rgb"].shape == (t_views, hh, ww, 3) and ret["outputs_coarse"]["depth"].shape == (t_views, hh, ww, 1)
+    torch.testing.assert_close(ret["outputs_coarse"]["rgb"].view(-1, 3), one["outputs_coarse"]["rgb"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ret["outputs_coarse"]["depth"].view(-1), one["outputs_coarse"]["depth"], rtol=1e-5, atol=1e-6)
+    assert ret["gt_rgb"].shape == (t_views, hh, ww, 3) and ret["gt_depth"].shape == (t_views, hh, ww, 1)
