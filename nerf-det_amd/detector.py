@@ -8,7 +8,7 @@ from torch import nn
 
 from . import ops
 from .boxes import DepthInstance3DBoxes, bbox3d2result
-from .nerf_mlp import VanillaNeRFRadianceField
+from .radiance_field import VanillaNeRFRadianceField
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 from .volume import extract_volume
 

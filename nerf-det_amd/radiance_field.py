@@ -1,0 +1,130 @@
+"""NeRF radiance-field MLP with the reference's parameter names.
+
+Mirror of mmdet3d/models/model_utils/nerf_mlp.py (MLP :11-90, NerfMLP :103-161, SinusoidalEncoder
+:164-197, VanillaNeRFRadianceField :200-234): same constructor arguments, same state-dict keys
+(``posi_encoder.scales``, ``mlp.base.hidden_layers.N.*``, ``mlp.sigma_layer.output_layer.*``,
+``mlp.bottleneck_layer.output_layer.*``, ``mlp.rgb_layer.*``) so released checkpoints load, same
+math.  On the GPU the encoder + concat run in one HIP kernel (ops.posenc_concat); the dense
+layers are library GEMMs (hipBLASLt through torch).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class LayerStack(nn.Module):
+    """``depth`` x (Linear + ReLU) of width ``width``; after hidden layer i with i % skip == 0 (i > 0) the
+    stack input is concatenated back; optional final Linear to ``out_dim``.  Xavier-uniform weights,
+    zero biases (nerf_mlp.py:60-78)."""
+
+    def __init__(self, in_dim: int, out_dim: Optional[int], depth: int, width: int, skip: Optional[int]):
+        super().__init__()
+        self.in_dim, self.skip, self.depth = in_dim, skip, depth
+        self.hidden_layers = nn.ModuleList()
+        feed = in_dim
+        for i in range(depth):
+            self.hidden_layers.append(nn.Linear(feed, width))
+            feed = width + in_dim if self._rejoin(i) else width
+        self.out_features = feed if out_dim is None else out_dim
+        if out_dim is not None:
+            self.output_layer = nn.Linear(feed, out_dim)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def _rejoin(self, i: int) -> bool:
+        return self.skip is not None and i > 0 and i % self.skip == 0
+
+    def forward(self, x):
+        x0 = x
+        for i, layer in enumerate(self.hidden_layers):
+            x = F.relu(layer(x))
+            if self._rejoin(i):
+                x = torch.cat([x, x0], dim=-1)
+        if hasattr(self, "output_layer"):
+            x = self.output_layer(x)
+        return x
+
+
+class NerfMLP(nn.Module):
+    """Trunk + sigma head + (bottleneck, view-conditioned rgb head).  nerf_mlp.py:103-161."""
+
+    def __init__(self, input_dim: int, condition_dim: int, feature_dim: int = 0, net_depth: int = 8, net_width: int = 256,
+                 skip_layer: int = 4, net_depth_condition: int = 1, net_width_condition: int = 128):
+        super().__init__()
+        self.base = LayerStack(input_dim + feature_dim, None, net_depth, net_width, skip_layer)
+        hid = self.base.out_features
+        self.sigma_layer = LayerStack(hid, 1, 0, net_width, None)
+        if condition_dim > 0:
+            self.bottleneck_layer = LayerStack(hid, net_width, 0, net_width, None)
+            self.rgb_layer = LayerStack(net_width + condition_dim, 3, net_depth_condition, net_width_condition, None)
+        else:
+            self.rgb_layer = LayerStack(hid, 3, 0, net_width, None)
+
+    def _trunk(self, x, features):
+        return self.base(x if features is None else torch.cat([x, features], dim=-1))
+
+    def query_density(self, x, features=None):
+        return self.sigma_layer(self._trunk(x, features))
+
+    def forward(self, x, condition=None, features=None):
+        h = self._trunk(x, features)
+        raw_sigma = self.sigma_layer(h)
+        if condition is None:
+            return self.rgb_layer(h), raw_sigma
+        if condition.shape[:-1] != h.shape[:-1]:  # one view direction per ray, broadcast over its samples
+            r, d = condition.shape
+            condition = condition.view([r] + [1] * (h.dim() - 2) + [d]).expand(*h.shape[:-1], d)
+        return self.rgb_layer(torch.cat([self.bottleneck_layer(h), condition], dim=-1)), raw_sigma
+
+
+class SinusoidalEncoder(nn.Module):
+    """``[x | sin(2^k x) | sin(2^k x + pi/2)]`` for k in [min_deg, max_deg).  nerf_mlp.py:164-197."""
+
+    def __init__(self, x_dim: int, min_deg: int, max_deg: int, use_identity: bool = True):
+        super().__init__()
+        self.x_dim, self.min_deg, self.max_deg, self.use_identity = x_dim, min_deg, max_deg, use_identity
+        self.register_buffer("scales", torch.tensor([2 ** i for i in range(min_deg, max_deg)]))
+
+    @property
+    def latent_dim(self) -> int:
+        return (int(self.use_identity) + 2 * (self.max_deg - self.min_deg)) * self.x_dim
+
+    def forward(self, x):
+        if self.max_deg == self.min_deg:
+            return x
+        xb = (x[..., None, :] * self.scales[:, None]).reshape(*x.shape[:-1], -1)
+        enc = torch.sin(torch.cat([xb, xb + 0.5 * math.pi], dim=-1))
+        return torch.cat([x, enc], dim=-1) if self.use_identity else enc
+
+
+class VanillaNeRFRadianceField(nn.Module):
+    """nerf_mlp.py:200-234."""
+
+    def __init__(self, net_depth: int = 8, net_width: int = 256, skip_layer: int = 4, feature_dim: int = 0,
+                 net_depth_condition: int = 1, net_width_condition: int = 128):
+        super().__init__()
+        self.posi_encoder = SinusoidalEncoder(3, 0, 10, True)
+        self.view_encoder = SinusoidalEncoder(3, 0, 4, True)
+        self.mlp = NerfMLP(self.posi_encoder.latent_dim, self.view_encoder.latent_dim, feature_dim, net_depth, net_width,
+                           skip_layer, net_depth_condition, net_width_condition)
+
+    def query_density(self, x, features=None):
+        return F.relu(self.mlp.query_density(self.posi_encoder(x), features))
+
+    def raw_sigma_from_rows(self, rows):
+        """sigma-MLP on pre-assembled ``[posenc | features]`` rows (ops.posenc_concat); no relu."""
+        return self.mlp.sigma_layer(self.mlp.base(rows))
+
+    def forward(self, x, condition=None, features=None):
+        x = self.posi_encoder(x)
+        if condition is not None:
+            condition = self.view_encoder(condition)
+        rgb, sigma = self.mlp(x, condition=condition, features=features)
+        return torch.sigmoid(rgb), F.relu(sigma)

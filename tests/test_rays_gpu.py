@@ -13,7 +13,7 @@ ATOL = 2e-5
 
 
 def _mlp(g, device):
-    from nerfdet_amd.nerf_mlp import VanillaNeRFRadianceField
+    from nerfdet_amd.radiance_field import VanillaNeRFRadianceField
     sd = sub_state(g, "nerf_mlp.")
     width = sd["mlp.base.hidden_layers.0.weight"].shape[0]
     fdim = sd["mlp.base.hidden_layers.0.weight"].shape[1] - 63

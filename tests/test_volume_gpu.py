@@ -127,7 +127,7 @@ def test_density_features_vs_oracle(device, name):
 @pytest.mark.parametrize("name", ["volume_small_s0", "volume_small_s1", "volume_medium_s2"])
 def test_extract_volume_matches_reference_golden(device, name):
     """Whole A1-A6 chain on the GPU == the real reference's nerfdet.extract_feat output (golden)."""
-    from nerfdet_amd.nerf_mlp import VanillaNeRFRadianceField
+    from nerfdet_amd.radiance_field import VanillaNeRFRadianceField
     from nerfdet_amd.volume import extract_volume
     g = load_golden(name)
     meta = golden_meta(g)
