@@ -92,60 +92,39 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes
 
 __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long* __restrict__ mask, const int* __restrict__ order,
                                                   int n, int64_t* __restrict__ keep, int64_t* __restrict__ n_keep) {
-    __shared__ int ord_s[NMS_MAX];     // sorted -> original index
-    __shared__ int kept_idx[NMS_MAX];  // picks, written out coalesced at the end
     const int lane = threadIdx.x;
     const int words = (n + 63) / 64;  // <= 64
-    const int wl = min(lane, words - 1);
-    for (int i = lane; i < n; i += 64) ord_s[i] = order[i];
-    __syncthreads();
-    unsigned long long removed = 0ull;  // lane w holds bits [64w, 64w+64) of the removed-set
-    // The walk is strictly serial (pick i depends on every earlier pick), so memory latency is taken off it: while the 64
-    // serial steps of chunk c run on registers only (v_readlane + bit test + OR, ~30 cycles each) the 64 rows of chunk
-    // c+1 are in flight.  Those prefetch loads are inline asm so that hipcc's automatic s_waitcnt placement does not see
-    // them (it would wait vmcnt(0) at every step); they are retired by ONE explicit wait per chunk.  Loads are
-    // unconditional (row index clamped); words left of the diagonal were never written by k_nms_mask and are masked out.
-    auto row_ptr = [&](int i) { return mask + (int64_t)min(i, n - 1) * words + wl; };
-    auto row_keep = [&](int i) { return i < n && lane < words && lane >= (i >> 6); };
-    unsigned long long cur[64], raw[64];
+    unsigned long long removed = 0ull;  // lane w holds bits [64w, 64w+64)
+    constexpr int PF = 8;
+    unsigned long long row[PF];
+    int ord[PF];  // original index of candidate i, prefetched with its row (a load inside the serial chain costs ~0.5 us per pick)
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        const unsigned long long* ptr = row_ptr(j);
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(raw[j]) : "v"(ptr));
+    for (int k = 0; k < PF; ++k) {
+        row[k] = (k < n && lane < words && lane >= k / 64) ? mask[(int64_t)k * words + lane] : 0ull;
+        ord[k] = k < n ? order[k] : 0;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 64; ++j) cur[j] = row_keep(j) ? raw[j] : 0ull;
     int kept = 0;
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        const int ordv = ord_s[min(c0 + lane, n - 1)];
+    for (int i0 = 0; i0 < n; i0 += PF) {
 #pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            const unsigned long long* ptr = row_ptr(c0 + 64 + j);
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(raw[j]) : "v"(ptr));
-        }
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            const int i = c0 + j;
+        for (int k = 0; k < PF; ++k) {
+            const int i = i0 + k;
             if (i < n) {
-                const unsigned half = (j & 32) ? (unsigned)(removed >> 32) : (unsigned)removed;
-                const unsigned wsel = (unsigned)__builtin_amdgcn_readlane((int)half, c0 >> 6);
-                if (!((wsel >> (j & 31)) & 1u)) {
-                    const int o = __builtin_amdgcn_readlane(ordv, j);
-                    if (lane == 0) kept_idx[kept] = o;
+                // word i/64 of the removed-set lives in lane i/64: a scalar v_readlane, not a cross-lane shuffle,
+                // keeps the serial dependence (removed -> gone -> removed) short
+                const unsigned half = (i & 32) ? (unsigned)(removed >> 32) : (unsigned)removed;
+                const unsigned wsel = (unsigned)__builtin_amdgcn_readlane((int)half, i >> 6);
+                const bool gone = (wsel >> (i & 31)) & 1u;
+                if (!gone) {
+                    if (lane == 0) keep[kept] = (int64_t)ord[k];
                     ++kept;
-                    removed |= cur[j];
+                    removed |= row[k];
                 }
             }
+            const int nx = i + PF;  // refill this slot; words left of the diagonal were never written -> skip them
+            row[k] = (nx < n && lane < words && lane >= nx / 64) ? mask[(int64_t)nx * words + lane] : 0ull;
+            ord[k] = nx < n ? order[nx] : 0;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 64; ++j) cur[j] = row_keep(c0 + 64 + j) ? raw[j] : 0ull;
     }
-    __syncthreads();
-    for (int i = lane; i < kept; i += 64) keep[i] = (int64_t)kept_idx[i];
     if (lane == 0) *n_keep = kept;
 }
 
