@@ -90,9 +90,16 @@ int ndet_alpha_gate(const float* mean, const float* density, const int64_t* coun
 /* alpha = 1 - exp(-relu(raw_sigma)) for N voxels (nerf_mlp.py:227 + nerfdet.py:257). */
 int ndet_sigma_to_alpha(const float* raw_sigma, float* alpha, int N, void* stream);
 
-/* A6 input assembly: rows [posenc(xyz) (63) | global (F)] for the sigma-MLP, nerf_mlp.py:181-197,140.
- * points (3,N) SoA; out (N, 63+F). */
-int ndet_posenc_concat(const float* points, const float* global_feat, int N, int F, float* out, void* stream);
+/* A6 input assembly: rows [posenc(xyz) (63) | global (F) | zero padding] for the sigma-MLP, nerf_mlp.py:181-197,140.
+ * points (3,N) SoA; out (N, out_stride), out_stride >= 63+F (a multiple of 32 when the rows feed the MFMA kernel). */
+int ndet_posenc_concat(const float* points, const float* global_feat, int N, int F, int out_stride, float* out,
+                       void* stream);
+
+/* A6 tail. sigma = w . [h | x] + b on the re-joined trunk output without materialising the concat (nerf_mlp.py:86,143),
+ * alpha = 1 - exp(-relu(sigma)) (nerf_mlp.py:227, nerfdet.py:257).  h (N,Ch); x (N, x_stride) of which the first Cx columns
+ * are used; w (Ch+Cx); bias: DEVICE scalar; raw_sigma (N) or NULL; alpha (N). */
+int ndet_sigma_head(const float* h, int Ch, const float* x, int Cx, int x_stride, const float* w, const float* bias,
+                    int N, float* raw_sigma, float* alpha, void* stream);
 
 /* A15. Greedy class-aware axis-aligned 3D NMS. Replaces aligned_3d_nms(),
  * mmdet3d/core/post_processing/box3d_nms.py:91-138 (pinned by the reference's tests/test_nms.py:5-58).

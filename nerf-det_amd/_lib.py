@@ -30,7 +30,8 @@ SIGNATURES = {
                                c_int64, _P, c_int, _P, _P, _P, _P], c_int),
     "ndet_alpha_gate": ([_P, _P, _P, _P, c_int, c_int, c_int, _P], c_int),
     "ndet_sigma_to_alpha": ([_P, _P, c_int, _P], c_int),
-    "ndet_posenc_concat": ([_P, _P, c_int, c_int, _P, _P], c_int),
+    "ndet_posenc_concat": ([_P, _P, c_int, c_int, c_int, _P, _P], c_int),
+    "ndet_sigma_head": ([_P, c_int, _P, c_int, c_int, _P, _P, c_int, _P, _P, _P], c_int),
     "ndet_nms_workspace_bytes": ([c_int], c_int64),
     "ndet_aligned_3d_nms": ([_P, _P, _P, c_int, c_float, _P, _P, _P, _P], c_int),
     "ndet_head_decode": ([_P, c_int, _P, _P, c_int, c_int, c_int, _F3, _F3, _P, _P, _P, _P], c_int),

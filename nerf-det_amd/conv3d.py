@@ -105,6 +105,33 @@ def packed(convs: Sequence[nn.Module], bn: Optional[nn.BatchNorm3d] = None):
     return val
 
 
+def packed_linear(lin: nn.Linear, pad_in_to: int = 0):
+    """nn.Linear as a 1x1 convolution for the MFMA kernel: weight (Cout, Cin) -> (1, Cout, Cin_padded), bias in the epilogue shift."""
+    store = lin.__dict__.setdefault("_ndet_packed", {})
+    stamp = (lin.weight.data_ptr(), lin.weight._version, None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version), pad_in_to)
+    hit = store.get("linear")
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    w = lin.weight.detach().float()
+    cout, cin = w.shape
+    width = max(cin, pad_in_to)
+    assert width % 32 == 0, f"input width {width} must be a multiple of 32"
+    if width > cin:
+        w = torch.cat([w, w.new_zeros(cout, width - cin)], dim=1)
+    scale = torch.ones(cout, device=w.device) if lin.bias is not None else None
+    shift = lin.bias.detach().float().contiguous() if lin.bias is not None else None
+    val = dict(w=w.unsqueeze(0).contiguous(), scale=scale, shift=shift, cout=cout, cin=width, ksize=1, stride=1, transposed=False,
+               kernel=(1, 1), strides=(1, 1), pads=(0, 0), ndim=2)
+    store["linear"] = (stamp, val)
+    return val
+
+
+def linear_rows(x: torch.Tensor, pk: dict, relu: int = 0) -> torch.Tensor:
+    """(M, Cin) rows -> (M, Cout): a Linear (+ ReLU) as one launch of the MFMA kernel (bias and ReLU in the epilogue)."""
+    assert x.dim() == 2 and x.is_contiguous()
+    return conv2d_nhwc(x.view(1, 1, x.shape[0], x.shape[1]), pk, relu=relu).view(x.shape[0], -1)
+
+
 def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = None, relu: int = 0, splits: int = 0, tile: int = 0):
     """x (D,H,W,Cin) contiguous fp32 on the GPU -> (OD,OH,OW,Cout).  relu: 0 none, 1 after the residual add, 2 before it."""
     if not x.is_cuda:

@@ -347,72 +347,70 @@ extern "C" int ndet_backproject_aggregate(const float* features_nhwc, int n_view
 // the second pass re-reads the same few rows from L1/L2.  Views outside the union of the two
 // validity masks all contribute the same constant and are folded in as n * const.
 // ------------------------------------------------------------------------------------------
+// Both validity masks and pixel offsets of one voxel for one 64-view round (lanes over views).
+struct DensityRound {
+    unsigned long long mf, mr;  // views seeing the voxel in the stride-4 map / in the full-resolution image
+    int off_f, off_r;           // per-lane (= per-view) offsets into the mapped map / one RGB plane
+};
+
+__device__ __forceinline__ DensityRound density_project(int v, int n_views, const float* __restrict__ proj, const float* __restrict__ rgb_proj,
+                                                        float px, float py, float pz, int w, int h, int W, int H, int mrow_pitch, int cm,
+                                                        int rsy) {
+    int xf = 0, yf = 0, xr = 0, yr = 0;
+    bool okf = false, okr = false;
+    if (v < n_views) {
+        okf = ndet_project(proj + v * 12, px, py, pz, w, h, xf, yf);
+        okr = ndet_project(rgb_proj + v * 12, px, py, pz, W, H, xr, yr);
+    }
+    DensityRound r;
+    r.off_f = yf * mrow_pitch + xf * cm;
+    r.off_r = yr * rsy + xr;
+    r.mf = __ballot(okf);
+    r.mr = __ballot(okr);
+    return r;
+}
+
+// One pass over the union of valid views of a round: PASS 0 accumulates values, PASS 1 squared deviations from `mean`.
 template <int PASS>
-__device__ __forceinline__ float density_pass(const float* __restrict__ mapped, int n_views, int cm, int h, int w,
-                                              int64_t mview_pitch, int mrow_pitch, const float* __restrict__ rgb, int H,
-                                              int W, int64_t rsv, int64_t rsc, int rsy, const float* __restrict__ proj,
-                                              const float* __restrict__ rgb_proj, float px, float py, float pz, int lane,
-                                              float fill, float mean, int& cnt_out) {
+__device__ __forceinline__ float density_round_pass(const DensityRound& d, int r0, const float* __restrict__ mapped, int64_t mview_pitch,
+                                                    const float* __restrict__ rgb, int64_t rsv, int64_t rsc, int lane, int cm, float fill,
+                                                    float mean, float acc) {
     const int ch = lane;
     const bool is_rgb = ch < 3;
     const bool active = ch < 3 + cm;
-    float acc = 0.0f;
-    int cnt = 0, n_union = 0;
-    for (int r0 = 0; r0 < n_views; r0 += 64) {
-        const int v = r0 + lane;
-        int xf = 0, yf = 0, xr = 0, yr = 0;
-        bool okf = false, okr = false;
-        if (v < n_views) {
-            okf = ndet_project(proj + v * 12, px, py, pz, w, h, xf, yf);
-            okr = ndet_project(rgb_proj + v * 12, px, py, pz, W, H, xr, yr);
-        }
-        const int off_f = yf * mrow_pitch + xf * cm;
-        const int off_r = yr * rsy + xr;
-        const unsigned long long mf = __ballot(okf), mr = __ballot(okr);
-        unsigned long long m = mf | mr;
-        cnt += __popcll(mf);
-        n_union += __popcll(m);
-        int b = 0;
-        while (m) {
-            float t[GATHER_BATCH];
-            bool has[GATHER_BATCH], mine[GATHER_BATCH];
+    unsigned long long m = d.mf | d.mr;
+    int b = 0;
+    while (m) {
+        float t[GATHER_BATCH];
+        bool has[GATHER_BATCH], mine[GATHER_BATCH];
 #pragma unroll
-            for (int k = 0; k < GATHER_BATCH; ++k) {
-                has[k] = (m != 0ull);
-                if (has[k]) {
-                    b = __builtin_ctzll(m);
-                    m &= (m - 1ull);
-                }
-                const bool vf = (mf >> b) & 1ull, vr = (mr >> b) & 1ull;
-                const int of = __builtin_amdgcn_readlane(off_f, b);
-                const int orr = __builtin_amdgcn_readlane(off_r, b);
-                mine[k] = active && (is_rgb ? vr : vf);
-                const float* p = is_rgb ? (rgb + (int64_t)(r0 + b) * rsv + (int64_t)ch * rsc + orr)
-                                        : (mapped + (int64_t)(r0 + b) * mview_pitch + of + (ch - 3));
-                t[k] = mine[k] ? *p : 0.0f;
+        for (int k = 0; k < GATHER_BATCH; ++k) {
+            has[k] = (m != 0ull);
+            if (has[k]) {
+                b = __builtin_ctzll(m);
+                m &= (m - 1ull);
             }
+            const bool vf = (d.mf >> b) & 1ull, vr = (d.mr >> b) & 1ull;
+            const int of = __builtin_amdgcn_readlane(d.off_f, b);
+            const int orr = __builtin_amdgcn_readlane(d.off_r, b);
+            mine[k] = active && (is_rgb ? vr : vf);
+            const float* p = is_rgb ? (rgb + (int64_t)(r0 + b) * rsv + (int64_t)ch * rsc + orr)
+                                    : (mapped + (int64_t)(r0 + b) * mview_pitch + of + (ch - 3));
+            t[k] = mine[k] ? *p : 0.0f;
+        }
 #pragma unroll
-            for (int k = 0; k < GATHER_BATCH; ++k) {
-                if (has[k]) {
-                    const float val = mine[k] ? t[k] : fill;
-                    if (PASS == 0) {
-                        acc = acc + val;
-                    } else {
-                        const float d = val - mean;
-                        acc = acc + d * d;
-                    }
+        for (int k = 0; k < GATHER_BATCH; ++k) {
+            if (has[k]) {
+                const float val = mine[k] ? t[k] : fill;
+                if (PASS == 0) {
+                    acc = acc + val;
+                } else {
+                    const float dd = val - mean;
+                    acc = acc + dd * dd;
                 }
             }
         }
     }
-    const float rest = (float)(n_views - n_union);
-    if (PASS == 0) {
-        acc = acc + rest * fill;
-    } else {
-        const float d = fill - mean;
-        acc = acc + rest * (d * d);
-    }
-    cnt_out = cnt;
     return acc;
 }
 
@@ -422,29 +420,57 @@ __global__ __launch_bounds__(256) void k_density_features(const float* __restric
                                                           int rsy, const float* __restrict__ points, int N,
                                                           const float* __restrict__ proj, const float* __restrict__ rgb_proj,
                                                           float* __restrict__ out, int n_tiles) {
+    constexpr int VPW = VOX_PER_TILE / 4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int tile = ndet_xcd_remap(blockIdx.x, n_tiles);
     const int F = 2 * (3 + cm);
     const float fill = (lane >= 3 && lane < 3 + cm) ? bias[lane - 3] : 0.0f;
-    for (int j = 0; j < VOX_PER_TILE / 4; ++j) {
+    const bool single_round = n_views <= 64;  // the common case: projections are computed once and reused by both passes
+
+    float px[VPW], py[VPW], pz[VPW];
+    bool live[VPW];
+#pragma unroll
+    for (int j = 0; j < VPW; ++j) {
         const int n = tile * VOX_PER_TILE + j * 4 + wave;
-        if (n >= N) continue;
-        const float px = points[n], py = points[N + n], pz = points[2 * N + n];
-        int cnt = 0;
-        const float sum = density_pass<0>(mapped, n_views, cm, h, w, mview_pitch, mrow_pitch, rgb, H, W, rsv, rsc, rsy, proj,
-                                          rgb_proj, px, py, pz, lane, fill, 0.0f, cnt);
+        live[j] = n < N;
+        const int nn = live[j] ? n : 0;
+        px[j] = points[nn]; py[j] = points[N + nn]; pz[j] = points[2 * N + nn];
+    }
+    // the wave's 4 voxels are projected back to back (lanes over views) before any gather is issued
+    DensityRound first[VPW];
+#pragma unroll
+    for (int j = 0; j < VPW; ++j) first[j] = density_project(lane, n_views, proj, rgb_proj, px[j], py[j], pz[j], w, h, W, H, mrow_pitch, cm, rsy);
+
+#pragma unroll
+    for (int j = 0; j < VPW; ++j) {
+        if (!live[j]) continue;
+        const int n = tile * VOX_PER_TILE + j * 4 + wave;
+        float sum = 0.0f;
+        int cnt = 0, n_union = 0;
+        for (int r0 = 0; r0 < n_views; r0 += 64) {
+            const DensityRound d = (r0 == 0) ? first[j]
+                                             : density_project(r0 + lane, n_views, proj, rgb_proj, px[j], py[j], pz[j], w, h, W, H, mrow_pitch, cm, rsy);
+            cnt += __popcll(d.mf);
+            n_union += __popcll(d.mf | d.mr);
+            sum = density_round_pass<0>(d, r0, mapped, mview_pitch, rgb, rsv, rsc, lane, cm, fill, 0.0f, sum);
+        }
+        const float rest = (float)(n_views - n_union);
+        sum = sum + rest * fill;
         const float denom = (float)cnt + 1e-8f;
         const float mean = sum / denom;  // NOT zeroed at cnt == 0 (nerfdet.py:241)
-        const float ss = density_pass<1>(mapped, n_views, cm, h, w, mview_pitch, mrow_pitch, rgb, H, W, rsv, rsc, rsy, proj,
-                                         rgb_proj, px, py, pz, lane, fill, mean, cnt);
+        float ss = 0.0f;
+        for (int r0 = 0; r0 < n_views; r0 += 64) {
+            const DensityRound d = (r0 == 0 || single_round) ? first[j]
+                                                             : density_project(r0 + lane, n_views, proj, rgb_proj, px[j], py[j], pz[j], w, h, W, H, mrow_pitch, cm, rsy);
+            ss = density_round_pass<1>(d, r0, mapped, mview_pitch, rgb, rsv, rsc, lane, cm, fill, mean, ss);
+        }
+        const float dd = fill - mean;
+        ss = ss + rest * (dd * dd);
         float var = ss / denom;
         if (cnt == 0) var = 1e6f;  // nerfdet.py:249
         const float cov = expf(-var);
-        if (lane < 3 + cm) {
-            float2 mc = make_float2(mean, cov);
-            *reinterpret_cast<float2*>(out + (int64_t)n * F + 2 * lane) = mc;
-        }
+        if (lane < 3 + cm) *reinterpret_cast<float2*>(out + (int64_t)n * F + 2 * lane) = make_float2(mean, cov);
     }
 }
 
@@ -508,13 +534,15 @@ extern "C" int ndet_alpha_gate(const float* mean, const float* density, const in
 }
 
 __global__ __launch_bounds__(256) void k_posenc_concat(const float* __restrict__ points, const float* __restrict__ glob, int N,
-                                                       int F, float* __restrict__ out) {
-    const int K = 63 + F;
+                                                       int F, int K, float* __restrict__ out) {
+    // K = row stride >= 63 + F; columns beyond 63 + F are zero (padding to the MFMA kernel's 32-channel K step)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * K) return;
     const int n = (int)(i / K), col = (int)(i % K);
     float r;
-    if (col >= 63) {
+    if (col >= 63 + F) {
+        r = 0.0f;
+    } else if (col >= 63) {
         r = glob[(int64_t)n * F + (col - 63)];
     } else if (col < 3) {
         r = points[col * N + n];
@@ -530,12 +558,48 @@ __global__ __launch_bounds__(256) void k_posenc_concat(const float* __restrict__
     out[i] = r;
 }
 
-extern "C" int ndet_posenc_concat(const float* points, const float* global_feat, int N, int F, float* out, void* stream) {
+extern "C" int ndet_posenc_concat(const float* points, const float* global_feat, int N, int F, int out_stride, float* out, void* stream) {
     NDET_REQUIRE(points && out && (global_feat || F == 0), NDET_E_INVALID, "ndet_posenc_concat: null pointer");
-    NDET_REQUIRE(N > 0 && F >= 0, NDET_E_INVALID, "ndet_posenc_concat: bad sizes");
-    const int64_t total = (int64_t)N * (63 + F);
+    NDET_REQUIRE(N > 0 && F >= 0 && out_stride >= 63 + F, NDET_E_INVALID, "ndet_posenc_concat: bad sizes");
+    const int64_t total = (int64_t)N * out_stride;
     hipLaunchKernelGGL(k_posenc_concat, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, points,
-                       global_feat, N, F, out);
+                       global_feat, N, F, out_stride, out);
     NDET_CHECK_LAUNCH("ndet_posenc_concat");
+    return NDET_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// A6 tail: sigma = w . [h | x] + b over the re-joined trunk output (nerf_mlp.py:86,143: the skip concat after the last
+// hidden layer feeds the 389 -> 1 sigma layer), then alpha = 1 - exp(-relu(sigma)) (nerf_mlp.py:227, nerfdet.py:257).
+// One wavefront per row; the concat is never materialised.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sigma_head(const float* __restrict__ h, int Ch, const float* __restrict__ x, int Cx, int x_stride,
+                                                    const float* __restrict__ w, const float* __restrict__ bias, int N,
+                                                    float* __restrict__ raw_sigma, float* __restrict__ alpha) {
+    const int lane = threadIdx.x & 63;
+    const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (n >= N) return;
+    float acc = 0.0f;
+    for (int c = lane; c < Ch; c += 64) acc = fmaf(h[(int64_t)n * Ch + c], w[c], acc);
+    for (int c = lane; c < Cx; c += 64) acc = fmaf(x[(int64_t)n * x_stride + c], w[Ch + c], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+        const float sg = acc + bias[0];
+        if (raw_sigma) raw_sigma[n] = sg;
+        alpha[n] = 1.0f - expf(-fmaxf(sg, 0.0f));
+    }
+}
+
+extern "C" int ndet_sigma_head(const float* h, int Ch, const float* x, int Cx, int x_stride, const float* w, const float* bias, int N,
+                               float* raw_sigma, float* alpha, void* stream) {
+    const char* fn = "ndet_sigma_head";
+    NDET_REQUIRE(h && x && w && bias && alpha, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(N > 0 && Ch > 0 && Cx >= 0 && x_stride >= Cx, NDET_E_INVALID, "%s: bad sizes", fn);
+    const int64_t blocks = ((int64_t)N + 3) / 4;
+    hipLaunchKernelGGL(k_sigma_head, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, h, Ch, x, Cx, x_stride, w, bias, N, raw_sigma,
+                       alpha);
+    NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }

@@ -218,9 +218,9 @@ def alpha_gate(mean: Tensor, density: Tensor, count: Tensor) -> Tensor:
     return out
 
 
-def posenc_concat(points: Tensor, global_feat: Optional[Tensor]) -> Tensor:
-    """Input rows of the sigma-MLP: ``[posenc_10(xyz) (63) | global_feat]`` (nerf_mlp.py:181-197,140).
-    ``points`` (3,X,Y,Z) or (3,N)."""
+def posenc_concat(points: Tensor, global_feat: Optional[Tensor], pad_to: int = 0) -> Tensor:
+    """Input rows of the sigma-MLP: ``[posenc_10(xyz) (63) | global_feat | zeros]`` (nerf_mlp.py:181-197,140).
+    ``points`` (3,X,Y,Z) or (3,N); ``pad_to`` widens the rows with zero columns (K-step padding for the MFMA kernel)."""
     _need_gpu(points, global_feat)
     p = _f32c(points).reshape(3, -1)
     n = p.shape[1]
@@ -229,6 +229,21 @@ def posenc_concat(points: Tensor, global_feat: Optional[Tensor]) -> Tensor:
         global_feat = _f32c(global_feat)
         assert global_feat.shape[0] == n
         f = global_feat.shape[1]
-    out = torch.empty((n, 63 + f), dtype=torch.float32, device=p.device)
-    check(_lib.load().ndet_posenc_concat(_ptr(p), _ptr(global_feat), n, f, _ptr(out), _stream(p)), "posenc_concat")
+    width = max(63 + f, pad_to)
+    out = torch.empty((n, width), dtype=torch.float32, device=p.device)
+    check(_lib.load().ndet_posenc_concat(_ptr(p), _ptr(global_feat), n, f, width, _ptr(out), _stream(p)), "posenc_concat")
     return out
+
+
+def sigma_head(h: Tensor, rows: Tensor, n_in: int, weight: Tensor, bias: Tensor, want_raw: bool = False):
+    """alpha = 1 - exp(-relu(w . [h | rows[:, :n_in]] + b)) per row (nerf_mlp.py:86,143,227; nerfdet.py:257)."""
+    _need_gpu(h, rows, weight, bias)
+    assert h.is_contiguous() and rows.is_contiguous() and h.shape[0] == rows.shape[0]
+    n, ch = h.shape
+    w = _f32c(weight).reshape(-1)
+    assert w.numel() == ch + n_in
+    alpha = torch.empty((n,), dtype=torch.float32, device=h.device)
+    raw = torch.empty((n,), dtype=torch.float32, device=h.device) if want_raw else None
+    check(_lib.load().ndet_sigma_head(_ptr(h), ch, _ptr(rows), n_in, rows.shape[1], _ptr(w), _ptr(_f32c(bias)), n, _ptr(raw), _ptr(alpha),
+                                      _stream(h)), "sigma_head")
+    return (alpha, raw) if want_raw else alpha

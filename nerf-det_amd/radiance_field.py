@@ -122,6 +122,29 @@ class VanillaNeRFRadianceField(nn.Module):
         """sigma-MLP on pre-assembled ``[posenc | features]`` rows (ops.posenc_concat); no relu."""
         return self.mlp.sigma_layer(self.mlp.base(rows))
 
+    def hip_trunk_ok(self) -> bool:
+        """The shipped architecture (4 hidden layers, input re-joined after the last one, widths % 32 == 0): its trunk runs
+        as 4 launches of the MFMA kernel + one fused sigma/alpha kernel."""
+        b = self.mlp.base
+        return (b.depth == 4 and b.skip == 3 and all(l.out_features % 32 == 0 for l in b.hidden_layers)
+                and not hasattr(b, "output_layer") and len(self.mlp.sigma_layer.hidden_layers) == 0)
+
+    def alpha_from_points(self, points, global_feat):
+        """Inference: voxel points (3,N)/(3,X,Y,Z) + conditioning rows (N,F) -> alpha (N) = 1-exp(-relu(sigma)), all in
+        hand-written kernels: posenc+concat (zero-padded to a multiple of 32), 4 x [Linear+ReLU] on the fp32 matrix cores,
+        fused sigma head.  nerf_mlp.py:224-227 + nerfdet.py:255-257."""
+        from . import ops
+        from .conv3d import linear_rows, packed_linear
+        b = self.mlp.base
+        n_in = 63 + global_feat.shape[1]
+        width = (n_in + 31) // 32 * 32
+        rows = ops.posenc_concat(points, global_feat, pad_to=width)
+        h = rows
+        for i, lin in enumerate(b.hidden_layers):
+            h = linear_rows(h, packed_linear(lin, pad_in_to=width if i == 0 else 0), relu=1)
+        out = self.mlp.sigma_layer.output_layer
+        return ops.sigma_head(h, rows, n_in, out.weight, out.bias)
+
     def forward(self, x, condition=None, features=None):
         x = self.posi_encoder(x)
         if condition is not None:

@@ -34,6 +34,16 @@ def map_features_2d(features: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
     return F.linear(rows, weight, bias).permute(0, 3, 1, 2)
 
 
+def map_features_2d_hip(features: Tensor, lin: torch.nn.Linear) -> Tensor:
+    """Inference form of :func:`map_features_2d`: the Linear as a 1x1 launch of the MFMA kernel (bias in the epilogue)."""
+    from .conv3d import conv2d_nhwc, packed_linear
+    f = ops.to_channels_last(features)
+    rows = f.permute(0, 2, 3, 1)
+    if not rows.is_contiguous():
+        rows = rows.contiguous()
+    return conv2d_nhwc(rows, packed_linear(lin)).permute(0, 3, 1, 2)
+
+
 def scene_geometry(img_meta: dict, n_voxels, voxel_size, stride: int, device) -> Dict[str, Tensor]:
     """Per-scene constants of the path (A1 + A2): stride-4 / stride-1 projections and the voxel lattice, on the GPU."""
     return dict(proj=ops.compute_projection(img_meta, stride, device), rgb_proj=ops.compute_projection(img_meta, 1, device),
@@ -52,16 +62,22 @@ def density_alpha(features: Tensor, denorm_images: Tensor, img_meta: dict, n_vox
         geometry = scene_geometry(img_meta, n_voxels, voxel_size, stride, dev)
     proj, rgb_proj, pts = geometry["proj"], geometry["rgb_proj"], geometry["points"]
     lin = mapping[0] if isinstance(mapping, torch.nn.Sequential) else mapping
+    training = torch.is_grad_enabled() and (feat.requires_grad or lin.weight.requires_grad)
     if feature_2d is None:
-        feature_2d = map_features_2d(feat, lin.weight, lin.bias)
+        if not training and lin.in_features % 32 == 0:
+            feature_2d = map_features_2d_hip(feat, lin)
+        else:
+            feature_2d = map_features_2d(feat, lin.weight, lin.bias)
     rgb = denorm_images[:, :, :img_meta["img_shape"][0], :img_meta["img_shape"][1]]
     out = dict(feat=feat, feature_2d=feature_2d, points=pts, projection=proj, rgb_projection=rgb_proj, rgb=rgb, lin=lin)
-    if torch.is_grad_enabled() and (feat.requires_grad or lin.weight.requires_grad):
-        return out  # training: the caller continues under autograd
+    if training:
+        return out  # the caller continues under autograd
     glob = ops.density_features(feature_2d, lin.bias, rgb, pts, proj, rgb_proj)
-    rows = ops.posenc_concat(pts, glob)
-    raw_sigma = nerf_mlp.raw_sigma_from_rows(rows)
-    out.update(global_feat=glob, raw_sigma=raw_sigma, alpha=ops.sigma_to_alpha(raw_sigma))
+    if hasattr(nerf_mlp, "hip_trunk_ok") and nerf_mlp.hip_trunk_ok():
+        out.update(global_feat=glob, raw_sigma=None, alpha=nerf_mlp.alpha_from_points(pts, glob))
+    else:  # other MLP shapes: library GEMMs
+        raw_sigma = nerf_mlp.raw_sigma_from_rows(ops.posenc_concat(pts, glob))
+        out.update(global_feat=glob, raw_sigma=raw_sigma, alpha=ops.sigma_to_alpha(raw_sigma))
     return out
 
 

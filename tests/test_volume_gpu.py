@@ -262,3 +262,25 @@ def test_cfg5_scale_sampled_voxels_and_properties(device):
     assert torch.equal(cnt2, cnt) and torch.equal(got2, 0.5 * got)     # linear in alpha (exact: x0.5)
     plain, _ = ops.backproject_aggregate(f, dp, dj, None, False)
     torch.testing.assert_close(plain * alpha.view(1, *grid).to(device), got, rtol=0, atol=1e-6)
+
+
+def test_sigma_mlp_on_matrix_cores_vs_oracle(device):
+    """alpha_from_points (posenc+concat, 4 x Linear+ReLU on the fp32 MFMA kernel, fused sigma head) at the shipped
+    width (133 -> 256 x4 -> [389 -> 1]) against the oracle's query_density."""
+    from nerfdet_amd.radiance_field import VanillaNeRFRadianceField
+    torch.manual_seed(0)
+    mlp = VanillaNeRFRadianceField(4, 256, 3, 70, 1, 128)
+    with torch.no_grad():
+        for p in mlp.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    assert mlp.hip_trunk_ok()
+    n = 5000
+    pts = torch.rand(3, n) * 6 - 3
+    glob = torch.randn(n, 70)
+    ref = 1 - torch.exp(-O.nerf_query_density(mlp.state_dict(), pts.t().contiguous(), glob))
+    mlp.to(device)
+    with torch.no_grad():
+        got = mlp.alpha_from_points(pts.to(device), glob.to(device))
+    assert (ref > 0).float().mean() > 0.2
+    torch.testing.assert_close(got.cpu(), ref.reshape(-1), rtol=0, atol=ATOL)
