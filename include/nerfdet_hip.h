@@ -180,6 +180,12 @@ int ndet_conv_ndhwc(const float* in, const float* w_packed, float* out, int D, i
                     const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
                     void* workspace, void* stream);
 
+/* ResNet stem tail in one pass: BatchNorm(eval) as per-channel scale/shift + ReLU + MaxPool(3, stride 2, pad 1) on the
+ * channels-last stem output x (N,H,W,C), C % 4 == 0 -> out (N, (H-1)/2+1, (W-1)/2+1, C).  Third-party mmdet ResNet stem
+ * (SURVEY.md appendix C), called at mmdet3d/models/detectors/nerfdet.py:140. */
+int ndet_bn_relu_maxpool_nhwc(const float* x, const float* scale, const float* shift, int N, int H, int W, int C,
+                              float* out, void* stream);
+
 /* ---- backward passes (training).  The reference obtains these from autograd over its materialised tensors; each
  * entry point names the forward statement it differentiates.  Scatter targets must be zero-initialised by the caller;
  * accumulation uses float atomics (order not fixed). ---- */

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .conv3d import conv2d_nhwc, packed
+from .conv3d import bn_relu_maxpool_nhwc, conv2d_nhwc, packed
 from .registry import BACKBONES, NECKS
 
 
@@ -124,8 +124,8 @@ class ResNet(nn.Module):
     use_hip = True  # inference on the GPU: bottlenecks through the fused MFMA convolution (csrc/conv3d_kernels.hip)
 
     def forward_hip(self, x):
-        x = F.relu(self.bn1(self.conv1(x)), inplace=True)  # 7x7 stem (Cin = 3) stays on the vendor library
-        x = _nhwc(F.max_pool2d(x, 3, 2, 1))
+        # the 7x7 stem conv (Cin = 3) stays on the vendor library; BN + ReLU + max-pool follow in one pass
+        x = bn_relu_maxpool_nhwc(_nhwc(self.conv1(x)), self.bn1)
         outs = []
         for i in range(self.num_stages):
             for blk in getattr(self, f"layer{i + 1}"):

@@ -194,6 +194,23 @@ def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = No
     return out
 
 
+def bn_relu_maxpool_nhwc(x: torch.Tensor, bn: nn.BatchNorm2d) -> torch.Tensor:
+    """x (N,H,W,C) contiguous -> MaxPool2d(3,2,1)(relu(bn_eval(x))) in one pass (ResNet stem tail)."""
+    assert x.is_cuda and x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+    n, h, w, c = x.shape
+    store = bn.__dict__.setdefault("_ndet_packed", {})
+    stamp = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    hit = store.get("affine")
+    if hit is None or hit[0] != stamp:
+        hit = (stamp, fold_bn(bn, None, c, x.device))
+        store["affine"] = hit
+    scale, shift = hit[1]
+    out = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
+    st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    check(_lib.load().ndet_bn_relu_maxpool_nhwc(_ptr(x), _ptr(scale), _ptr(shift), n, h, w, c, _ptr(out), st), "bn_relu_maxpool_nhwc")
+    return out
+
+
 def to_ndhwc(x: torch.Tensor) -> torch.Tensor:
     """logical (C,X,Y,Z) -> contiguous (X,Y,Z,C) (free when the memory already is channels-last)."""
     y = x.permute(1, 2, 3, 0)

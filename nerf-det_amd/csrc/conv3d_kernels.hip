@@ -409,3 +409,50 @@ extern "C" int ndet_conv3d_ndhwc(const float* in, const float* w_packed, float* 
     p.res_up2 = 0; p.RH = p.RW = 0;
     return conv_launch(p, tile, (hipStream_t)stream, fn);
 }
+
+// ------------------------------------------------------------------------------------------------
+// ResNet stem tail in one pass: eval-mode BatchNorm (scale/shift) + ReLU + 3x3 stride-2 pad-1 max-pool on the 7x7 stem
+// convolution's channels-last output (the stem conv itself, Cin = 3, stays on the vendor library).
+// Replaces three elementwise passes over the largest activation of the network (245 MB at cfg2).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bn_relu_maxpool(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         int N, int H, int W, int C, int OH, int OW, float* __restrict__ out) {
+    const int c4n = C >> 2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * OH * OW * c4n) return;
+    const int c4 = (int)(i % c4n);
+    const int ow = (int)((i / c4n) % OW), oh = (int)((i / ((int64_t)c4n * OW)) % OH), n = (int)(i / ((int64_t)c4n * OW * OH));
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c4 * 4), sh = *reinterpret_cast<const float4*>(shift + c4 * 4);
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);  // ReLU output is >= 0 and every window holds at least one real pixel
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int y = 2 * oh + dy;
+        if (y < 0 || y >= H) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = 2 * ow + dx;
+            if (xx < 0 || xx >= W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(x + (((int64_t)n * H + y) * W + xx) * C + c4 * 4);
+            m.x = fmaxf(m.x, v.x * sc.x + sh.x);
+            m.y = fmaxf(m.y, v.y * sc.y + sh.y);
+            m.z = fmaxf(m.z, v.z * sc.z + sh.z);
+            m.w = fmaxf(m.w, v.w * sc.w + sh.w);
+        }
+    }
+    *reinterpret_cast<float4*>(out + i * 4) = m;
+}
+
+extern "C" int ndet_bn_relu_maxpool_nhwc(const float* x, const float* scale, const float* shift, int N, int H, int W, int C, float* out,
+                                         void* stream) {
+    const char* fn = "ndet_bn_relu_maxpool_nhwc";
+    NDET_REQUIRE(x && scale && shift && out, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
+    NDET_REQUIRE(C % 4 == 0 && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0, NDET_E_UNSUPPORTED,
+                 "%s: C must be a multiple of 4 and pointers 16-byte aligned", fn);
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * OH * OW * (C / 4);
+    hipLaunchKernelGGL(k_bn_relu_maxpool, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, N, H, W, C,
+                       OH, OW, out);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
