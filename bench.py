@@ -50,15 +50,16 @@ def k1_algorithmic_bytes(w):
 def k1_measured_traffic(workload):
     """HBM-side bytes per K1 launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled as the
     gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE); None when no profile matches the workload."""
-    path = os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        if d.get("workload") == workload:
-            return int(d["k1"]["traffic_bytes"])
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), reverse=True):  # newest round first
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d.get("workload") == workload:
+                return int(d["k1"]["traffic_bytes"]), os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
 
 
 def synth_batch(w, seed):
@@ -266,6 +267,7 @@ def main():
     k1_ms = sorted(a.elapsed_time(b) for a, b in k1_events)
     k1_avg_ms = sum(k1_ms) / len(k1_ms)
     abytes = k1_algorithmic_bytes(w)
+    k1_traffic, k1_traffic_src = k1_measured_traffic(args.workload)
     achieved = abytes / (k1_avg_ms * 1e-3) / 1e9
     stages = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in stage_events.items()}
     conv_ms = [a.elapsed_time(b) for _, a, b in conv_events]
@@ -300,8 +302,8 @@ def main():
                          "sampled_steps": n_conv_steps},
             "roofline_projection": {"kernel": "k_backproject_aggregate (fused backproject + view mean/count + alpha gating)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": k1_measured_traffic(args.workload),
-                         "traffic_source": "profiles/r01_c_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": k1_traffic,
+                         "traffic_source": f"{k1_traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                          "algorithmic_bytes": abytes,
                          "avg_launch_ms": k1_avg_ms, "median_launch_ms": k1_ms[len(k1_ms) // 2]},
             "execution": "hipGraph replay (2 graphs) + eager K1 + eager post-processing" if args.graph else "eager launches",

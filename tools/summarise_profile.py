@@ -1,0 +1,93 @@
+"""Turn rocprofv3 output directories into the summaries committed under profiles/.
+
+  python tools/summarise_profile.py stats  <kernel-trace dir> <out.csv> [--last-steps K --steps-total T]
+  python tools/summarise_profile.py pmc    <FETCH_SIZE dir> <WRITE_SIZE dir> <out.json>
+
+`stats` groups the kernel trace by (shortened) kernel name: launches, average / total duration, share of GPU time.
+`pmc` averages FETCH_SIZE / WRITE_SIZE (KB) per kernel and derives the projection kernel's HBM traffic the way
+MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE doubled for wide coalesced reads, WRITE_SIZE exact).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import OrderedDict
+
+
+def short(name: str) -> str:
+    name = name.strip('"')
+    for cut in ("(", ):
+        if cut in name and not name.startswith("void k_") and not name.startswith("k_"):
+            name = name.split(cut)[0]
+    return name[:96]
+
+
+def find(d, pat):
+    hits = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+    if not hits:
+        raise SystemExit(f"no {pat} under {d}")
+    return hits[0]
+
+
+def stats(trace_dir, out_csv, header=""):
+    rows = list(csv.DictReader(open(find(trace_dir, "*kernel_trace.csv"))))
+    agg = OrderedDict()
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        a = agg.setdefault(k, [0, 0.0, 1e30, 0.0])
+        a[0] += 1
+        a[1] += d
+        a[2] = min(a[2], d)
+        a[3] = max(a[3], d)
+    total = sum(a[1] for a in agg.values())
+    with open(out_csv, "w") as f:
+        if header:
+            f.write(f"# {header}\n")
+        f.write("kernel,launches,avg_us,min_us,max_us,total_ms,percent\n")
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            f.write(f"\"{k}\",{a[0]},{a[1] / a[0]:.2f},{a[2]:.2f},{a[3]:.2f},{a[1] / 1e3:.3f},{100 * a[1] / total:.2f}\n")
+    print(f"wrote {out_csv}: {len(agg)} kernels, {total / 1e3:.1f} ms of GPU time")
+
+
+def counter(d, name):
+    agg = OrderedDict()
+    for r in csv.DictReader(open(find(d, "*counter_collection.csv"))):
+        if r["Counter_Name"] != name:
+            continue
+        a = agg.setdefault(short(r["Kernel_Name"]), [0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return {k: {"launches": a[0], "avg_kb": a[1] / a[0]} for k, a in agg.items()}
+
+
+def pmc(fetch_dir, write_dir, out_json, command="", workload="cfg2", algorithmic_bytes=None):
+    f = counter(fetch_dir, "FETCH_SIZE")
+    w = counter(write_dir, "WRITE_SIZE")
+    k1 = next(k for k in f if "k_backproject_aggregate" in k and "bwd" not in k)
+    traffic = int(round((2.0 * f[k1]["avg_kb"] + w[k1]["avg_kb"]) * 1024))
+    out = {
+        "command": command,
+        "note": "gfx950: FETCH_SIZE counts 64 B per 128-B request on wide (16 B/lane) coalesced reads -> doubled for the projection "
+                "kernel (MI355X_MICROARCH.md, HBM); WRITE_SIZE is exact. Counters are L2 memory-side (fabric) requests; "
+                "Infinity-Cache hits are included.",
+        "workload": workload,
+        "k1": {"kernel": k1, "fetch_kb_raw": f[k1]["avg_kb"], "write_kb": w[k1]["avg_kb"], "traffic_bytes": traffic,
+               "algorithmic_bytes": algorithmic_bytes},
+        "per_kernel_raw_kb": {"FETCH_SIZE": f, "WRITE_SIZE": w},
+    }
+    json.dump(out, open(out_json, "w"), indent=1)
+    print(f"wrote {out_json}: K1 traffic {traffic / 1e6:.1f} MB per launch")
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    if mode == "stats":
+        stats(sys.argv[2], sys.argv[3], header=" ".join(sys.argv[4:]))
+    elif mode == "pmc":
+        extra = sys.argv[5:]
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], command=extra[0] if extra else "",
+            algorithmic_bytes=int(extra[1]) if len(extra) > 1 else None)
+    else:
+        raise SystemExit(__doc__)
