@@ -15,7 +15,22 @@ from torch import nn
 
 from . import _lib
 from ._lib import check
-from .conv_tuning import TUNED
+from .conv_tuning import TUNED, TUNED_SPLIT
+
+# Arithmetic of the convolution kernels: "bf16x3" = fp32 operands split exactly into three bf16 terms, six bf16-MFMA
+# products accumulated in fp32 (csrc/conv_split_kernels.hip; fp32-level error, 16x the MFMA rate per product);
+# "f32" = the fp32-input MFMA kernel (csrc/conv3d_kernels.hip; bit-exact FMA chains).
+ARITHMETIC = "f32"
+
+
+def set_arithmetic(mode: str) -> str:
+    """Select the kernel family for every following convolution launch; returns the previous mode."""
+    global ARITHMETIC
+    if mode not in ("f32", "bf16x3"):
+        raise ValueError(f"unknown conv arithmetic {mode!r}")
+    prev, ARITHMETIC = ARITHMETIC, mode
+    return prev
+
 
 launch_hook = None  # bench.py: callable(flops, thunk) wrapping every MFMA-conv launch (event timing); None = direct
 
@@ -45,6 +60,57 @@ def choose_tiling(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 
         while splits < 8 and k_iters // (splits + 1) >= 64 and tiles * (splits + 1) <= cap:
             splits += 1
     return tile, splits
+
+
+def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 0, transposed: bool = False):
+    """Tile (64 = 64x64, 128 = 128x128, 12864 = 128 rows x 64 channels) and split-K factor for the bf16x3 kernel."""
+    if tile == 0 and splits == 0:
+        hit = TUNED_SPLIT.get((m, cout, k_iters, int(transposed)))
+        if hit is not None:
+            return hit
+    if tile == 0:
+        big = ((m + 127) // 128) * ((cout + 127) // 128)
+        if big >= 120 and cout > 64:
+            tile = 128
+        elif cout <= 64 and (m + 127) // 128 >= 256:
+            tile = 12864
+        else:
+            tile = 64
+    if splits == 0:
+        if transposed:
+            return tile, 1
+        tm, tn = (128, 64) if tile == 12864 else (tile, tile)
+        tiles = ((m + tm - 1) // tm) * ((cout + tn - 1) // tn)
+        splits = 1
+        while splits < 8 and k_iters // (splits + 1) >= 32 and tiles * (splits + 1) <= 1024:
+            splits += 1
+    return tile, splits
+
+
+def split_planes(pk: dict) -> torch.Tensor:
+    """The packed weight as three bf16 planes (3, taps, Cout, Cin) with w = p0 + p1 + p2 exactly (built once per pack)."""
+    planes = pk.get("w_split")
+    if planes is None:
+        w = pk["w"]
+        planes = torch.empty((3,) + tuple(w.shape), dtype=torch.int16, device=w.device)
+        st = c_void_p(torch.cuda.current_stream(w.device).cuda_stream)
+        check(_lib.load().ndet_split_bf16x3(_ptr(w), w.numel(), _ptr(planes), st), "split_bf16x3")
+        pk["w_split"] = planes
+    return planes
+
+
+def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, residual_up2, relu, splits, tile, m, k_iters, flops):
+    tile, splits = choose_tiling_split(m, pk["cout"], k_iters, tile, 1 if (transposed or residual_up2) else splits, transposed)
+    ws = torch.empty((m * pk["cout"] * splits * 4,), dtype=torch.uint8, device=x.device) if splits > 1 else None
+    i3 = lambda v: (ctypes.c_int * 3)(*v)
+    st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    lib = _lib.load()
+    planes = split_planes(pk)
+    d, h, w = dims
+    _launch(flops, lambda: check(lib.ndet_conv_ndhwc_split(_ptr(x), _ptr(planes), _ptr(out), d, h, w, pk["cin"], pk["cout"], i3(kernel), i3(stride),
+                                                          i3(pad), int(transposed), _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual),
+                                                          int(residual_up2), relu, splits, tile, _ptr(ws), st), "conv_ndhwc_split"))
+    return out
 
 
 def _ptr(t):
@@ -150,6 +216,11 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
         assert residual.shape == out.shape and residual.is_contiguous()
     lib = _lib.load()
     m = d * h * w if tr else od * oh * ow
+    flops = 2 * m * cout * cin * (1 if tr else k ** 3) * (8 if tr else 1)
+    if ARITHMETIC == "bf16x3":
+        kk, ss, pp = ((2, 2, 2), (2, 2, 2), (0, 0, 0)) if tr else ((k,) * 3, (s,) * 3, (k // 2,) * 3)
+        return _conv_split(x, pk, out, (d, h, w), kk, ss, pp, tr, residual, False, relu, splits, tile, m,
+                           (cin // 32) * (1 if tr else k ** 3), flops)
     if tr:
         tile, splits = (tile or choose_tiling(m, cout, cin // 32, 0, 0, True)[0]), 1
     else:
@@ -158,7 +229,6 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
     if splits > 1:
         ws = torch.empty((int(lib.ndet_conv3d_workspace_bytes(d, h, w, cin, cout, k, s, splits)),), dtype=torch.uint8, device=x.device)
     st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-    flops = 2 * m * cout * cin * (1 if tr else k ** 3) * (8 if tr else 1)
     _launch(flops, lambda: check(lib.ndet_conv3d_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), d, h, w, cin, cout, k, s, int(tr), _ptr(pk["scale"]),
                                                        _ptr(pk["shift"]), _ptr(residual), relu, splits, tile, _ptr(ws), st), "conv3d_ndhwc"))
     return out
@@ -182,6 +252,9 @@ def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = No
         if residual_up2:
             splits = 1
     m = n * oh * ow
+    if ARITHMETIC == "bf16x3":
+        return _conv_split(x, pk, out, (n, h, w), (1, kh, kw), (1, sh, sw), (0, ph, pw), False, residual, residual_up2, relu, splits, tile, m,
+                           kh * kw * (cin // 32), 2 * m * cout * cin * kh * kw)
     tile, splits = choose_tiling(m, cout, kh * kw * (cin // 32), tile, splits)
     ws = torch.empty((m * cout * splits * 4,), dtype=torch.uint8, device=x.device) if splits > 1 else None
     i3 = lambda a, b, c: (ctypes.c_int * 3)(a, b, c)

@@ -32,3 +32,8 @@ TUNED = {
     (240000, 256, 8, 0): (128, 1),  # fpn.lat0 1x1 256->256: 327 us
     (240000, 256, 72, 0): (128, 1),  # fpn.out0 3x3 256->256: 2337 us
 }
+
+
+# (M, Cout, K-steps, transposed) -> (tile, splits) for the bf16x3 kernel (csrc/conv_split_kernels.hip); filled from
+# tools/tune_conv_split.py sweeps on MI355X
+TUNED_SPLIT = {}

@@ -16,37 +16,16 @@
 //
 // Replaces nn.Conv3d / nn.ConvTranspose3d(k=2,s=2) + BatchNorm3d(eval) + ReLU of
 // mmdet3d/models/necks/imvoxelnet.py:8-67,233-260 and the head convs of dense_heads/imvoxel_head_v2.py:45-49.
-#include "ndet_common.hpp"
+#include "conv_common.hpp"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define CBK 32          // K step (input channels per step)
 // LDS row stride in floats.  A lane (row = l & 15, k-group g = l >> 4) reads 16 B at row*LD + 4g; ds_read_b128 is served
 // in 16-lane groups {0-3,12-15,20-27},... over 64 banks.  LD = 40 makes the 16 starts of a group hit 16 distinct
 // 4-bank slots (conflict-free); LD = 36 leaves 2-way conflicts (measured: a third of the LDS cycles) but lets a
 // fourth 64x64 workgroup fit on the CU, which matters more for the small memory-bound layers.
 template <int BM> struct LdsStride { static constexpr int value = (BM >= 128) ? CBK + 8 : CBK + 4; };
 
-struct Conv3dParams {
-    const float* in;      // (D, H, W, Cin)
-    const float* w;       // packed (taps, Cout, Cin)
-    float* out;           // (OD, OH, OW, Cout)   [transposed: (2D, 2H, 2W, Cout)]
-    const float* scale;   // (Cout) or null
-    const float* shift;   // (Cout) or null
-    const float* res;     // same shape as out, or null
-    float* partial;       // split-K workspace (splits, M, Cout) or null
-    int D, H, W, Cin;
-    int OD, OH, OW, Cout;
-    int kd, kh, kw;       // kernel extent per axis (2D convolution: D = batch, kd = 1)
-    int sd, sh, sw;       // stride per axis
-    int pd, ph, pw;       // zero padding per axis
-    int relu;             // 0 none, 1 ReLU last (after the residual add), 2 ReLU before the residual add
-    int transposed;       // 1: ConvTranspose3d k=2 s=2 (blockIdx.z = tap)
-    int splits;           // split-K factor (blockIdx.z = split) when !transposed
-    int M;                // GEMM rows: output voxels (input voxels when transposed)
-    int res_up2;          // 1: residual is a (OD, ceil(OH/2), ceil(OW/2), Cout) map read at (d, h>>1, w>>1): nearest x2 upsample-add
-    int RH, RW;           //    its H and W
-};
 
 template <int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void k_conv3d_igemm(const Conv3dParams p) {
@@ -211,57 +190,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void k_co
                 Cs[(wm * WM + ta * 16 + (lane >> 4) * 4 + r) * CLDC + wn * WN + tb * 16 + (lane & 15)] = acc[ta][tb][r];
     __syncthreads();
 
-    const bool raw = (!p.transposed && p.splits > 1);
-    float* dst = raw ? p.partial + (int64_t)blockIdx.z * p.M * p.Cout : p.out;
-    auto res_row = [&](int m, int64_t orow) -> int64_t {
-        if (!p.res_up2) return orow;
-        const int ow = m % p.OW, oh = (m / p.OW) % p.OH, od = m / (p.OW * p.OH);
-        return ((int64_t)od * p.RH + (oh >> 1)) * p.RW + (ow >> 1);
-    };
-    auto out_row = [&](int m) -> int64_t {
-        if (!p.transposed) return m;
-        const int iw = m % p.W, ih = (m / p.W) % p.H, id = m / (p.W * p.H);
-        const int kd = ztap >> 2, kh = (ztap >> 1) & 1, kw = ztap & 1;
-        return ((int64_t)(2 * id + kd) * p.OH + (2 * ih + kh)) * p.OW + (2 * iw + kw);
-    };
-    if ((p.Cout & 3) == 0) {
-        constexpr int V = BN / 4;  // float4 pieces per tile row
-        for (int idx = tid; idx < BM * V; idx += NTHR) {
-            const int row = idx / V, c4 = idx % V;
-            const int m = m0 + row, co = n0 + c4 * 4;
-            if (m >= p.M || co >= p.Cout) continue;
-            const int64_t o = out_row(m) * p.Cout + co;
-            float4 v = *reinterpret_cast<const float4*>(Cs + row * CLDC + c4 * 4);
-            if (!raw) {
-                if (p.scale) {
-                    const float4 sc = *reinterpret_cast<const float4*>(p.scale + co), sh = *reinterpret_cast<const float4*>(p.shift + co);
-                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                }
-                if (p.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (p.res) {
-                    const float4 rr = *reinterpret_cast<const float4*>(p.res + res_row(m, out_row(m)) * p.Cout + co);
-                    v.x = v.x + rr.x; v.y = v.y + rr.y; v.z = v.z + rr.z; v.w = v.w + rr.w;
-                }
-                if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            }
-            *reinterpret_cast<float4*>(dst + o) = v;
-        }
-    } else {  // Cout not a multiple of 4 (the fused head conv, Cout = 25): scalar columns
-        for (int idx = tid; idx < BM * BN; idx += NTHR) {
-            const int row = idx / BN, c = idx % BN;
-            const int m = m0 + row, co = n0 + c;
-            if (m >= p.M || co >= p.Cout) continue;
-            const int64_t o = out_row(m) * p.Cout + co;
-            float v = Cs[row * CLDC + c];
-            if (!raw) {
-                if (p.scale) v = v * p.scale[co] + p.shift[co];
-                if (p.relu == 2) v = fmaxf(v, 0.0f);
-                if (p.res) v = v + p.res[res_row(m, out_row(m)) * p.Cout + co];
-                if (p.relu == 1) v = fmaxf(v, 0.0f);
-            }
-            dst[o] = v;
-        }
-    }
+    conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0, BM, n0, tid, ztap, blockIdx.z);
 }
 
 // fixed-order reduction of the split-K partials + epilogue
@@ -319,7 +248,7 @@ static int conv_launch_tile(const Conv3dParams& p, hipStream_t st, const char* f
     return NDET_OK;
 }
 
-static int conv_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn) {
+int conv_f32_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn) {
     const int Cout = p.Cout;
     const int64_t big_tiles = (int64_t)((p.M + 127) / 128) * ((Cout + 127) / 128);
     if (tile == 0) tile = (big_tiles >= 256 && Cout >= 128) ? 128 : 64;
@@ -331,13 +260,16 @@ static int conv_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn
     }
     if (rc != NDET_OK) return rc;
     NDET_CHECK_LAUNCH(fn);
-    if (!p.transposed && p.splits > 1) {
-        const int64_t mn = (int64_t)p.M * Cout;
-        const int64_t work = (Cout & 3) == 0 ? mn / 4 : mn;
-        hipLaunchKernelGGL(k_conv3d_splitk_reduce, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, p.partial, p.splits, mn, Cout, p.scale,
-                           p.shift, p.res, p.relu, p.out);
-        NDET_CHECK_LAUNCH(fn);
-    }
+    return conv_splitk_reduce_launch(p, st, fn);
+}
+
+int conv_splitk_reduce_launch(const Conv3dParams& p, hipStream_t st, const char* fn) {
+    if (p.transposed || p.splits <= 1) return NDET_OK;
+    const int64_t mn = (int64_t)p.M * p.Cout;
+    const int64_t work = (p.Cout & 3) == 0 ? mn / 4 : mn;
+    hipLaunchKernelGGL(k_conv3d_splitk_reduce, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, p.partial, p.splits, mn, p.Cout, p.scale,
+                       p.shift, p.res, p.relu, p.out);
+    NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
 
@@ -373,7 +305,7 @@ extern "C" int ndet_conv_ndhwc(const float* in, const float* w_packed, float* ou
     const int iters = p.kd * p.kh * p.kw * (Cin / CBK);
     NDET_REQUIRE(p.splits <= iters, NDET_E_INVALID, "%s: splits=%d exceeds the %d K steps", fn, p.splits, iters);
     NDET_REQUIRE(p.splits == 1 || workspace != nullptr, NDET_E_INVALID, "%s: split-K needs a workspace", fn);
-    return conv_launch(p, tile, (hipStream_t)stream, fn);
+    return conv_f32_launch(p, tile, (hipStream_t)stream, fn);
 }
 
 extern "C" int64_t ndet_conv3d_workspace_bytes(int D, int H, int W, int Cin, int Cout, int ksize, int stride, int splits) {
@@ -407,7 +339,7 @@ extern "C" int ndet_conv3d_ndhwc(const float* in, const float* w_packed, float* 
     p.M = D * H * W;
     p.splits = 1;
     p.res_up2 = 0; p.RH = p.RW = 0;
-    return conv_launch(p, tile, (hipStream_t)stream, fn);
+    return conv_f32_launch(p, tile, (hipStream_t)stream, fn);
 }
 
 // ------------------------------------------------------------------------------------------------

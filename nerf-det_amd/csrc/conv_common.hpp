@@ -1,0 +1,93 @@
+// Shared by the two implicit-GEMM convolution kernels (conv3d_kernels.hip: exact fp32 MFMA; conv_split_kernels.hip:
+// fp32 operands split into three bf16 terms on the bf16 matrix cores).
+#pragma once
+#include "ndet_common.hpp"
+
+#define CBK 32          // K step (input channels per step)
+
+struct Conv3dParams {
+    const float* in;      // (D, H, W, Cin)
+    const float* w;       // packed (taps, Cout, Cin)
+    float* out;           // (OD, OH, OW, Cout)   [transposed: (2D, 2H, 2W, Cout)]
+    const float* scale;   // (Cout) or null
+    const float* shift;   // (Cout) or null
+    const float* res;     // same shape as out, or null
+    float* partial;       // split-K workspace (splits, M, Cout) or null
+    int D, H, W, Cin;
+    int OD, OH, OW, Cout;
+    int kd, kh, kw;       // kernel extent per axis (2D convolution: D = batch, kd = 1)
+    int sd, sh, sw;       // stride per axis
+    int pd, ph, pw;       // zero padding per axis
+    int relu;             // 0 none, 1 ReLU last (after the residual add), 2 ReLU before the residual add
+    int transposed;       // 1: ConvTranspose3d k=2 s=2 (blockIdx.z = tap)
+    int splits;           // split-K factor (blockIdx.z = split) when !transposed
+    int M;                // GEMM rows: output voxels (input voxels when transposed)
+    int res_up2;          // 1: residual is a (OD, ceil(OH/2), ceil(OW/2), Cout) map read at (d, h>>1, w>>1): nearest x2 upsample-add
+    int RH, RW;           //    its H and W
+};
+
+// internal launchers (one per kernel family) and the shared split-K reduction
+int conv_f32_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn);
+int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn);
+int conv_splitk_reduce_launch(const Conv3dParams& p, hipStream_t st, const char* fn);
+
+// Output row of GEMM row m (identity; the k2 s2 transposed convolution scatters tap `ztap` of input voxel m).
+__device__ __forceinline__ int64_t conv_out_row(const Conv3dParams& p, int m, int ztap) {
+    if (!p.transposed) return m;
+    const int iw = m % p.W, ih = (m / p.W) % p.H, id = m / (p.W * p.H);
+    const int kd = ztap >> 2, kh = (ztap >> 1) & 1, kw = ztap & 1;
+    return ((int64_t)(2 * id + kd) * p.OH + (2 * ih + kh)) * p.OW + (2 * iw + kw);
+}
+
+// Fused epilogue over `rows` rows of a C tile staged in LDS (row stride cld floats, BN columns): per-channel scale/shift,
+// ReLU before or after the residual add, residual (optionally a half-resolution map read nearest-upsampled), or raw
+// split-K partials.  Threads own float4 pieces along Cout so global traffic is whole rows.
+template <int BN, int NTHR>
+__device__ __forceinline__ void conv_store_rows(const Conv3dParams& p, const float* Cs, int cld, int m_first, int rows, int n0, int tid,
+                                                int ztap, int zsplit) {
+    const bool raw = (!p.transposed && p.splits > 1);
+    float* dst = raw ? p.partial + (int64_t)zsplit * p.M * p.Cout : p.out;
+    auto res_row = [&](int m, int64_t orow) -> int64_t {
+        if (!p.res_up2) return orow;
+        const int ow = m % p.OW, oh = (m / p.OW) % p.OH, od = m / (p.OW * p.OH);
+        return ((int64_t)od * p.RH + (oh >> 1)) * p.RW + (ow >> 1);
+    };
+    if ((p.Cout & 3) == 0) {
+        constexpr int V = BN / 4;
+        for (int idx = tid; idx < rows * V; idx += NTHR) {
+            const int row = idx / V, c4 = idx % V;
+            const int m = m_first + row, co = n0 + c4 * 4;
+            if (m >= p.M || co >= p.Cout) continue;
+            const int64_t orow = conv_out_row(p, m, ztap);
+            float4 v = *reinterpret_cast<const float4*>(Cs + row * cld + c4 * 4);
+            if (!raw) {
+                if (p.scale) {
+                    const float4 sc = *reinterpret_cast<const float4*>(p.scale + co), sh = *reinterpret_cast<const float4*>(p.shift + co);
+                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                }
+                if (p.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (p.res) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.res + res_row(m, orow) * p.Cout + co);
+                    v.x = v.x + rr.x; v.y = v.y + rr.y; v.z = v.z + rr.z; v.w = v.w + rr.w;
+                }
+                if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            *reinterpret_cast<float4*>(dst + orow * p.Cout + co) = v;
+        }
+    } else {  // Cout not a multiple of 4 (the fused head conv, Cout = 25): scalar columns
+        for (int idx = tid; idx < rows * BN; idx += NTHR) {
+            const int row = idx / BN, c = idx % BN;
+            const int m = m_first + row, co = n0 + c;
+            if (m >= p.M || co >= p.Cout) continue;
+            const int64_t orow = conv_out_row(p, m, ztap);
+            float v = Cs[row * cld + c];
+            if (!raw) {
+                if (p.scale) v = v * p.scale[co] + p.shift[co];
+                if (p.relu == 2) v = fmaxf(v, 0.0f);
+                if (p.res) v = v + p.res[res_row(m, orow) * p.Cout + co];
+                if (p.relu == 1) v = fmaxf(v, 0.0f);
+            }
+            dst[orow * p.Cout + co] = v;
+        }
+    }
+}

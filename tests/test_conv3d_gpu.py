@@ -36,8 +36,17 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=["f32", "bf16x3"])
+def arith(request):
+    """Run a test on both kernel families: fp32-input MFMA and the 3-term bf16 split on the bf16 matrix cores."""
+    from nerfdet_amd import conv3d
+    prev = conv3d.set_arithmetic(request.param)
+    yield request.param
+    conv3d.set_arithmetic(prev)
+
+
 @pytest.mark.parametrize("cin,cout,grid,k,stride,tr,use_bn,relu,use_res,splits,tile", CASES)
-def test_conv3d_matches_torch_fp32(device, cin, cout, grid, k, stride, tr, use_bn, relu, use_res, splits, tile):
+def test_conv3d_matches_torch_fp32(device, arith, cin, cout, grid, k, stride, tr, use_bn, relu, use_res, splits, tile):
     from nerfdet_amd.conv3d import conv3d_ndhwc, packed
     torch.manual_seed(cin * 7 + cout)
     if tr:
@@ -140,7 +149,7 @@ CASES_2D = [
 
 
 @pytest.mark.parametrize("cin,cout,nhw,k,stride,use_bn,relu,use_res", CASES_2D)
-def test_conv2d_nhwc_matches_torch_fp32(device, cin, cout, nhw, k, stride, use_bn, relu, use_res):
+def test_conv2d_nhwc_matches_torch_fp32(device, arith, cin, cout, nhw, k, stride, use_bn, relu, use_res):
     from nerfdet_amd.conv3d import conv2d_nhwc, packed
     torch.manual_seed(cin + cout + k)
     conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=not use_bn)
@@ -164,6 +173,39 @@ def test_conv2d_nhwc_matches_torch_fp32(device, cin, cout, nhw, k, stride, use_b
                           residual=None if res is None else res.permute(0, 2, 3, 1).contiguous().to(device), relu=relu)
     assert got.shape == ref.shape
     assert float((got.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("tile", [64, 128, 12864])
+def test_split_conv_is_fp32_accurate_against_fp64(device, tile):
+    """The 3-term bf16 split keeps fp32 accuracy: against an fp64 convolution its error is at the level of the
+    fp32-MFMA kernel's (and of the CPU fp32 convolution), orders below a plain bf16 product (~4e-3)."""
+    from nerfdet_amd import conv3d
+    torch.manual_seed(5)
+    conv = nn.Conv3d(256, 128, 3, 1, 1, bias=False)
+    x = torch.randn(12, 12, 8, 256) * torch.logspace(-3, 3, 256)  # channels spanning six decades
+    with torch.no_grad():
+        ref64 = F.conv3d(x.double().permute(3, 0, 1, 2).unsqueeze(0), conv.weight.double(), padding=1)[0].permute(1, 2, 3, 0)
+        ref32 = F.conv3d(x.permute(3, 0, 1, 2).unsqueeze(0), conv.weight, padding=1)[0].permute(1, 2, 3, 0)
+        pk = conv3d.packed([conv.to(device)])
+        prev = conv3d.set_arithmetic("bf16x3")
+        try:
+            got_split = conv3d.conv3d_ndhwc(x.to(device), pk, tile=tile, splits=1).cpu()
+        finally:
+            conv3d.set_arithmetic(prev)
+        got_f32 = conv3d.conv3d_ndhwc(x.to(device), pk, splits=1).cpu()
+    scale = float(ref64.abs().mean())
+    e_split = float((got_split.double() - ref64).abs().max()) / scale
+    e_f32 = float((got_f32.double() - ref64).abs().max()) / scale
+    e_cpu = float((ref32.double() - ref64).abs().max()) / scale
+    assert e_split <= 2.0 * max(e_f32, e_cpu) and e_split < 5e-6, (e_split, e_f32, e_cpu)
+
+
+def test_split_planes_sum_exactly(device):
+    from nerfdet_amd import conv3d
+    torch.manual_seed(6)
+    w = (torch.randn(1, 37, 64) * torch.logspace(-20, 20, 64)).to(device)
+    planes = conv3d.split_planes(dict(w=w)).view(torch.bfloat16).double()
+    assert torch.equal(planes.sum(0), w.double())
 
 
 def test_resnet_fpn_hip_matches_library(device):
