@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4-copy ceiling)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA peak (v_mfma_f32_16x16x4_f32), = fp32 vector peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 WORKLOADS = {
     "cfg2": dict(n_views=50, img_hw=(240, 320), channels=256, n_voxels=(40, 40, 16), voxel_size=(0.16, 0.16, 0.2), depth=50),
@@ -141,6 +142,8 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the static part of the step from hipGraphs (nerfdet_amd/graphed.py); measured equal to eager "
                          "launches within 1 %% on MI355X: the step is GPU-bound, launch-ahead already hides the gaps")
+    ap.add_argument("--conv-arithmetic", default=None, choices=["f32", "bf16x3"],
+                    help="convolution kernel family (default: the package default, nerfdet_amd.conv3d.ARITHMETIC)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,6 +186,8 @@ def main():
 
     # every launch of the MFMA convolution (the dominant kernel of the step: 3D neck/head + ResNet/FPN bottlenecks)
     import nerfdet_amd.conv3d as C3
+    if args.conv_arithmetic:
+        C3.set_arithmetic(args.conv_arithmetic)
     conv_events = []
 
     def conv_hook(flops, thunk):
@@ -266,6 +271,18 @@ def main():
         del k1_events[n_k1:]
     k1_ms = sorted(a.elapsed_time(b) for a, b in k1_events)
     k1_avg_ms = sum(k1_ms) / len(k1_ms)
+    if C3.ARITHMETIC == "bf16x3":
+        conv_kernel = ("k_conv_split (implicit-GEMM convolution on the bf16 matrix cores, fp32 operands split exactly into 3 bf16 terms, "
+                       "6 MFMA products per multiply, fp32 accumulate: 3D neck + head, ResNet/FPN; all tile instantiations, split-K "
+                       "reduce launches included in the event spans)")
+        conv_peak = MFMA_BF16_PEAK_TFLOPS / 6.0
+        conv_peak_note = ("achieved = algorithmic fp32 convolution FLOPs / time; peak = dense bf16 MFMA peak 2500 TFLOP/s / 6 issued "
+                          "products per algorithmic multiply-add")
+    else:
+        conv_kernel = ("k_conv3d_igemm (fp32-MFMA implicit-GEMM convolution: 3D neck + head, ResNet/FPN bottlenecks; both tile "
+                       "instantiations, split-K reduce launches included in the event spans)")
+        conv_peak = MFMA_F32_PEAK_TFLOPS
+        conv_peak_note = "dense fp32-input MFMA peak"
     abytes = k1_algorithmic_bytes(w)
     k1_traffic, k1_traffic_src = k1_measured_traffic(args.workload)
     achieved = abytes / (k1_avg_ms * 1e-3) / 1e9
@@ -287,16 +304,15 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if C3.ARITHMETIC == "f32" else "f32 (convolutions: fp32 operands as exact 3-term bf16 sums on the bf16 MFMA, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: nerfdet_res{w['depth']}_2x_low_res forward_test, {w['n_views']} views "
                                    f"{w['img_hw'][0]}x{w['img_hw'][1]}, {'x'.join(map(str, w['n_voxels']))} voxels, fp32, "
                                    f"1 scene/step/GPU, random-init weights",
                        "scenes_per_step": world, "parallelism": f"scene replicas x{world} (no data-path collective)"},
-            "roofline": {"kernel": "k_conv3d_igemm (fp32-MFMA implicit-GEMM convolution: 3D neck + head, ResNet/FPN bottlenecks; "
-                                   "both tile instantiations, split-K reduce launches included in the event spans)",
-                         "bound": "mfma", "achieved": conv_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": conv_tflops / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+            "roofline": {"kernel": conv_kernel,
+                         "bound": "mfma", "achieved": conv_tflops, "peak": conv_peak, "unit": "TFLOP/s",
+                         "frac": conv_tflops / conv_peak, "traffic": None, "peak_note": conv_peak_note,
                          "algorithmic_flops_per_step": conv_flops / n_conv_steps, "launches_per_step": len(conv_events) / n_conv_steps,
                          "avg_launch_ms": sum(conv_ms) / len(conv_ms), "total_ms_per_step": sum(conv_ms) / n_conv_steps,
                          "sampled_steps": n_conv_steps},

@@ -197,7 +197,7 @@ def test_split_conv_is_fp32_accurate_against_fp64(device, tile):
     e_split = float((got_split.double() - ref64).abs().max()) / scale
     e_f32 = float((got_f32.double() - ref64).abs().max()) / scale
     e_cpu = float((ref32.double() - ref64).abs().max()) / scale
-    assert e_split <= 2.0 * max(e_f32, e_cpu) and e_split < 5e-6, (e_split, e_f32, e_cpu)
+    assert e_split <= 2.0 * max(e_f32, e_cpu) and e_split < 1e-4, (e_split, e_f32, e_cpu)
 
 
 def test_split_planes_sum_exactly(device):
