@@ -180,15 +180,15 @@ int ndet_conv_ndhwc(const float* in, const float* w_packed, float* out, int D, i
                     const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
                     void* workspace, void* stream);
 
-/* fp32 array -> three bf16 planes (plane stride n elements) with x = p0 + p1 + p2 exactly (p0 = bf16(x), p1 = bf16(x - p0),
- * p2 = bf16(x - p0 - p1), round-to-nearest-even).  Prepares packed weights for ndet_conv_ndhwc_split (the conv weights
- * of necks/imvoxelnet.py:36-67 and dense_heads/imvoxel_head_v2.py:45-49). */
-int ndet_split_bf16x3(const float* x, int64_t n, uint16_t* planes, void* stream);
+/* Packed fp32 weights (taps, Cout, Cin) -> three bf16 planes tiled per 32-channel K step, (taps, Cin/32, 3, Cout, 32), with
+ * w = p0 + p1 + p2 exactly (p0 = bf16(w), p1 = bf16(w - p0), p2 = bf16(w - p0 - p1), round-to-nearest-even).  Prepares the
+ * weights of ndet_conv_ndhwc_split (the conv weights of necks/imvoxelnet.py:36-67, dense_heads/imvoxel_head_v2.py:45-49). */
+int ndet_split_weights_bf16x3(const float* w_packed, int taps, int Cout, int Cin, uint16_t* planes, void* stream);
 
 /* Same contract as ndet_conv_ndhwc / the transposed form of ndet_conv3d_ndhwc, computed on the bf16 matrix cores:
- * weights as three bf16 planes (3, taps, Cout, Cin) from ndet_split_bf16x3, activations split on the fly; the six
+ * weights as tiled bf16 planes (taps, Cin/32, 3, Cout, 32) from ndet_split_weights_bf16x3, activations split on the fly; the six
  * products of order <= 2 are accumulated in fp32 (error at the level of an fp32 FMA chain).  transposed = 1: k2 s2
- * ConvTranspose3d (kernel/stride must be 2, pad 0; weights (3, 8, Cout, Cin)).  tile: 0 auto, 64, 128, 12864 (128 x 64).
+ * ConvTranspose3d (kernel/stride must be 2, pad 0; 8 taps).  tile: 0 auto, 64, 128, 12864 (128 x 64).
  * Replaces the same reference modules as ndet_conv3d_ndhwc (necks/imvoxelnet.py:36-67,233-260,
  * dense_heads/imvoxel_head_v2.py:45-49) and the mmdet ResNet/FPN convolutions behind nerfdet.py:140. */
 int ndet_conv_ndhwc_split(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,

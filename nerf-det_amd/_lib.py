@@ -45,7 +45,7 @@ SIGNATURES = {
     "ndet_density_features_bwd": ([_P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, _P, _P, c_int, _P, _P, _P, _P], c_int),
     "ndet_ray_view_stats_bwd": ([_P, _P, c_int, _P, c_int, c_float, c_float, _P, c_int, c_int, c_int, c_int64, c_int64, _P, _P], c_int),
     "ndet_composite_bwd": ([_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P], c_int),
-    "ndet_split_bf16x3": ([_P, c_int64, _P, _P], c_int),
+    "ndet_split_weights_bf16x3": ([_P, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_conv_ndhwc_split": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_bn_relu_maxpool_nhwc": ([_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_conv3d_workspace_bytes": ([c_int] * 8, c_int64),

@@ -20,7 +20,7 @@ from .conv_tuning import TUNED, TUNED_SPLIT
 # Arithmetic of the convolution kernels: "bf16x3" = fp32 operands split exactly into three bf16 terms, six bf16-MFMA
 # products accumulated in fp32 (csrc/conv_split_kernels.hip; fp32-level error, 16x the MFMA rate per product);
 # "f32" = the fp32-input MFMA kernel (csrc/conv3d_kernels.hip; bit-exact FMA chains).
-ARITHMETIC = "f32"
+ARITHMETIC = "bf16x3"
 
 
 def set_arithmetic(mode: str) -> str:
@@ -63,7 +63,8 @@ def choose_tiling(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 
 
 
 def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 0, transposed: bool = False):
-    """Tile (64 = 64x64, 128 = 128x128, 12864 = 128 rows x 64 channels) and split-K factor for the bf16x3 kernel."""
+    """Tile (64 = 64x64, 128 = 128x128, 12864 = 128 rows x 64 channels, 128256 = wave-specialised 128 rows x 256 channels)
+    and split-K factor for the bf16x3 kernel."""
     if tile == 0 and splits == 0:
         hit = TUNED_SPLIT.get((m, cout, k_iters, int(transposed)))
         if hit is not None:
@@ -79,7 +80,7 @@ def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: 
     if splits == 0:
         if transposed:
             return tile, 1
-        tm, tn = (128, 64) if tile == 12864 else (tile, tile)
+        tm, tn = {12864: (128, 64), 128256: (128, 256)}.get(tile, (tile, tile))
         tiles = ((m + tm - 1) // tm) * ((cout + tn - 1) // tn)
         splits = 1
         while splits < 8 and k_iters // (splits + 1) >= 32 and tiles * (splits + 1) <= 1024:
@@ -88,13 +89,15 @@ def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: 
 
 
 def split_planes(pk: dict) -> torch.Tensor:
-    """The packed weight as three bf16 planes (3, taps, Cout, Cin) with w = p0 + p1 + p2 exactly (built once per pack)."""
+    """The packed weight (taps, Cout, Cin) as three bf16 planes tiled per 32-channel K step, (taps, Cin/32, 3, Cout, 32), with
+    w = p0 + p1 + p2 exactly (built once per pack)."""
     planes = pk.get("w_split")
     if planes is None:
         w = pk["w"]
-        planes = torch.empty((3,) + tuple(w.shape), dtype=torch.int16, device=w.device)
+        taps, cout, cin = w.shape
+        planes = torch.empty((taps, cin // 32, 3, cout, 32), dtype=torch.int16, device=w.device)
         st = c_void_p(torch.cuda.current_stream(w.device).cuda_stream)
-        check(_lib.load().ndet_split_bf16x3(_ptr(w), w.numel(), _ptr(planes), st), "split_bf16x3")
+        check(_lib.load().ndet_split_weights_bf16x3(_ptr(w), taps, cout, cin, _ptr(planes), st), "split_weights_bf16x3")
         pk["w_split"] = planes
     return planes
 

@@ -9,7 +9,9 @@
 // below one fp32 rounding of the product: the result carries the same error as an fp32 FMA chain (measured against
 // an fp64 convolution in tests/test_conv3d_gpu.py), at 6/16 of the fp32-MFMA issue time.
 //
-// Layout: weights arrive pre-split as three bf16 planes (3, taps, Cout, Cin) (ndet_split_bf16x3 below, once per model);
+// Layout: weights arrive pre-split as three bf16 planes, tiled per K step: (taps, Cin/32, 3, Cout, 32) -- the B tile of one
+// K step is one contiguous run per plane, so every staging load instruction covers 1 KB of whole cache lines
+// (ndet_split_weights_bf16x3 below, once per model);
 // activations stay fp32 channels-last in HBM and are split while they are staged into LDS.  LDS holds three bf16 planes
 // per operand, K-contiguous rows of 32 k (64 B) padded to 80 B so that the ds_read_b128 fragment reads (lane -> row
 // l & 31, k-octet l >> 5) fall on 16 distinct 16-byte slots per 16 lanes.  One LDS stage (60 KB at 128 x 128) with the
@@ -32,12 +34,12 @@ __device__ __forceinline__ uint32_t spl_pack(float x, float y) {
 __device__ __forceinline__ float spl_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float spl_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
-// 8 fp32 -> three planes of 8 bf16 (16 B each)
-__device__ __forceinline__ void spl_split8(const float4 lo, const float4 hi, uint4& p0, uint4& p1, uint4& p2) {
-    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    uint32_t o0[4], o1[4], o2[4];
+// 4 fp32 -> three planes of 4 bf16 (8 B each)
+__device__ __forceinline__ void spl_split4(const float4 v, uint2& p0, uint2& p1, uint2& p2) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o0[2], o1[2], o2[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
         const float a = x[2 * i], b = x[2 * i + 1];
         o0[i] = spl_pack(a, b);
         const float ra = a - spl_lo(o0[i]), rb = b - spl_hi(o0[i]);   // exact
@@ -45,18 +47,19 @@ __device__ __forceinline__ void spl_split8(const float4 lo, const float4 hi, uin
         const float sa = ra - spl_lo(o1[i]), sb = rb - spl_hi(o1[i]); // exact, <= 8 significant bits left
         o2[i] = spl_pack(sa, sb);
     }
-    p0 = make_uint4(o0[0], o0[1], o0[2], o0[3]);
-    p1 = make_uint4(o1[0], o1[1], o1[2], o1[3]);
-    p2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
+    p0 = make_uint2(o0[0], o0[1]);
+    p1 = make_uint2(o1[0], o1[1]);
+    p2 = make_uint2(o2[0], o2[1]);
 }
 
 template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dParams p, const uint16_t* __restrict__ wsplit, int64_t plane_elems) {
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dParams p, const uint16_t* __restrict__ wsplit) {
     constexpr int NTHR = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN;   // per-wave tile
     constexpr int MT = WM / 32, NT = WN / 32;     // 32x32 MFMA tiles per wave
-    constexpr int RPP = NTHR / 4;                 // tile rows staged per pass (4 threads x 8 k cover one 32-k row)
-    constexpr int AR = BM / RPP, BR = BN / RPP;
+    constexpr int RPA = NTHR / 8;                 // A rows staged per pass: 8 threads x 4 fp32 cover one 128-byte row
+    constexpr int RPB = NTHR / 4;                 // B rows staged per pass: 4 threads x 8 bf16 cover one 64-byte row
+    constexpr int AR = BM / RPA, BR = BN / RPB;
     static_assert(AR >= 1 && BR >= 1 && MT >= 1 && NT >= 1, "tile too small for the thread count");
     constexpr int APL = BM * SPL_RS, BPL = BN * SPL_RS;  // one plane, in bf16 elements
     extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
@@ -67,8 +70,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int kg = tid & 3;         // which 8-k octet of the 32-k run
-    const int srow = tid >> 2;      // 0..RPP-1
+    const int akq = tid & 7, arow_ = tid >> 3;   // A: 4-k quad and first row
+    const int bkg = tid & 3, brow_ = tid >> 2;   // B: 8-k octet and first row
 
     const int cin_steps = p.Cin / CBK;
     const int taps = p.transposed ? 1 : p.kd * p.kh * p.kw;
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
     bool vok[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int m = m0 + srow + RPP * i;
+        const int m = m0 + arow_ + RPA * i;
         vok[i] = m < p.M;
         const int mm = vok[i] ? m : 0;
         const int ow_ = p.transposed ? p.W : p.OW, oh_ = p.transposed ? p.H : p.OH;
@@ -104,73 +107,78 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 ra[AR][2];
+    float4 ra[AR];
     uint4 rb[BR][3];
-    const float* arow[AR];
-    const uint16_t* brow[BR];
-    int cur_tap = -1;
-    auto enter_tap = [&](int tap) {
-        cur_tap = tap;
-        const int kd = tap / (p.kh * p.kw), kh = (tap / p.kw) % p.kh, kw = tap % p.kw;
+    const int64_t wtile = (int64_t)p.Cout * CBK;   // one plane of one K step, in elements
+    bool bok[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) bok[i] = n0 + brow_ + RPB * i < p.Cout;
+    const uint16_t* bbase_g = wsplit + (int64_t)(n0 + brow_) * CBK + bkg * 8;
+    // K walk: channel chunk outermost, taps innermost -- consecutive steps re-read the same input rows shifted by one
+    // tap, so the A working set of a workgroup (its rows + halo, 32 channels) stays cache resident across the taps.
+    const int wkd = p.transposed ? 1 : p.kd, wkh = p.transposed ? 1 : p.kh, wkw = p.transposed ? 1 : p.kw;
+    int bd[AR], bh[AR], bw[AR];
+    const float* rowbase[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        bd[i] = p.transposed ? vd[i] : vd[i] * p.sd - p.pd;
+        bh[i] = p.transposed ? vh[i] : vh[i] * p.sh - p.ph;
+        bw[i] = p.transposed ? vw[i] : vw[i] * p.sw - p.pw;
+        rowbase[i] = p.in + (((int64_t)bd[i] * p.H + bh[i]) * p.W + bw[i]) * p.Cin + akq * 4;  // dereferenced only when in range
+    }
+    // state of the next tile to load
+    int nkd, nkh, nkw, ncs;
+    {
+        const int t0 = it_begin % taps;
+        ncs = it_begin / taps;
+        nkd = t0 / (wkh * wkw); nkh = (t0 / wkw) % wkh; nkw = t0 % wkw;
+    }
+    auto load_tile = [&]() {
+        const int tap = p.transposed ? ztap : (nkd * wkh + nkh) * wkw + nkw;
+        const int64_t toff = (((int64_t)nkd * p.H + nkh) * p.W + nkw) * p.Cin + ncs * CBK;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            int id, ih, iw;
-            if (p.transposed) {
-                id = vd[i]; ih = vh[i]; iw = vw[i];
-            } else {
-                id = vd[i] * p.sd + kd - p.pd;
-                ih = vh[i] * p.sh + kh - p.ph;
-                iw = vw[i] * p.sw + kw - p.pw;
-            }
-            const bool ok = vok[i] && id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            arow[i] = ok ? p.in + ((int64_t)(id * p.H + ih) * p.W + iw) * p.Cin + kg * 8 : nullptr;
+            const bool ok = vok[i] && (unsigned)(bd[i] + nkd) < (unsigned)p.D && (unsigned)(bh[i] + nkh) < (unsigned)p.H &&
+                            (unsigned)(bw[i] + nkw) < (unsigned)p.W;
+            const float4 v = *reinterpret_cast<const float4*>(ok ? rowbase[i] + toff : p.in + akq * 4);   // always issued
+            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const int co = n0 + srow + RPP * i;
-            brow[i] = co < p.Cout ? wsplit + ((int64_t)tap * p.Cout + co) * p.Cin + kg * 8 : nullptr;
-        }
-    };
-    auto load_tile = [&](int it) {
-        const int tap = p.transposed ? ztap : it / cin_steps;
-        if (tap != cur_tap) enter_tap(tap);
-        const int ci0 = (p.transposed ? it : it - tap * cin_steps) * CBK;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            ra[i][0] = ra[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (arow[i]) {
-                ra[i][0] = *reinterpret_cast<const float4*>(arow[i] + ci0);
-                ra[i][1] = *reinterpret_cast<const float4*>(arow[i] + ci0 + 4);
-            }
-        }
+        const uint16_t* bt = bbase_g + ((int64_t)tap * cin_steps + ncs) * 3 * wtile;
 #pragma unroll
         for (int i = 0; i < BR; ++i)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                rb[i][pl] = make_uint4(0u, 0u, 0u, 0u);
-                if (brow[i]) rb[i][pl] = *reinterpret_cast<const uint4*>(brow[i] + pl * plane_elems + ci0);
+                const uint4 v = *reinterpret_cast<const uint4*>(bok[i] ? bt + pl * wtile + (int64_t)RPB * i * CBK : wsplit + bkg * 8);
+                rb[i][pl] = bok[i] ? v : make_uint4(0u, 0u, 0u, 0u);
             }
+        if (++nkw == wkw) {
+            nkw = 0;
+            if (++nkh == wkh) {
+                nkh = 0;
+                if (++nkd == wkd) { nkd = 0; ++ncs; }
+            }
+        }
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            uint4 s0, s1, s2;
-            spl_split8(ra[i][0], ra[i][1], s0, s1, s2);
-            uint16_t* dst = As + (srow + RPP * i) * SPL_RS + kg * 8;
-            *reinterpret_cast<uint4*>(dst) = s0;
-            *reinterpret_cast<uint4*>(dst + APL) = s1;
-            *reinterpret_cast<uint4*>(dst + 2 * APL) = s2;
+            uint2 s0, s1, s2;
+            spl_split4(ra[i], s0, s1, s2);
+            uint16_t* dst = As + (arow_ + RPA * i) * SPL_RS + akq * 4;
+            *reinterpret_cast<uint2*>(dst) = s0;
+            *reinterpret_cast<uint2*>(dst + APL) = s1;
+            *reinterpret_cast<uint2*>(dst + 2 * APL) = s2;
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            uint16_t* dst = Bs + (srow + RPP * i) * SPL_RS + kg * 8;
+            uint16_t* dst = Bs + (brow_ + RPB * i) * SPL_RS + bkg * 8;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint4*>(dst + pl * BPL) = rb[i][pl];
         }
     };
 
     if (it_begin < it_end) {
-        load_tile(it_begin);
+        load_tile();
         store_tile();
     }
     __syncthreads();
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
     const uint16_t* bbase = Bs + (wn * WN + frow) * SPL_RS + fk;
     for (int it = it_begin; it < it_end; ++it) {
         const bool more = it + 1 < it_end;
-        if (more) load_tile(it + 1);
+        if (more) load_tile();
 #pragma unroll
         for (int ks = 0; ks < CBK / 16; ++ks) {
             bf16x8 fa[3][MT], fb[3][NT];
@@ -230,6 +238,250 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised 128 x 256 tile (the 256-channel layers of the neck and the FPN): 4 consumer waves (2 x 2, wave tile
+// 64 x 128: 96 MFMAs per K step, nothing else) + 4 producer waves (one per SIMD: loads, the A split, LDS fills of the
+// other of two stages).  Measured on the 128 x 128 tile: staging costs a wave ~2400 cycles per K step on its own (one
+// VALU instruction per >= 4 cycles), more than the 1536 MFMA cycles it feeds -- with 256 output channels the same A
+// split feeds 3072 MFMA cycles.  Producers keep two K steps in flight in a register ring; loads are buffer loads whose
+// out-of-range lanes (padding taps, rows past M, channels past Cout) return zeros in hardware, so a step costs the
+// producer one mask test per row and no address arithmetic (the tap / chunk walk lives in the scalar offset).
+// LDS rows are unpadded 64-byte runs (2 x 72 KB stages); the 16-byte chunk index is XORed with (row >> 2) & 3, which
+// spreads the 16 lanes of every ds_read_b128 group over all 16 slots of the 256-byte bank row.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define WS_BM 128
+#define WS_BN 256
+#define WS_DEPTH 2
+#define WS_OOB 0x80000000u
+
+__global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, const uint16_t* __restrict__ wsplit) {
+    constexpr int APL = WS_BM * CBK, BPL = WS_BN * CBK;   // one plane, in bf16 elements
+    constexpr int STAGE = 3 * (APL + BPL);
+    constexpr int AR = 4, BR = 4;                          // rows per producer thread: A 128 / 32, B 256 / 64
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the role branch and everything under it stay wave-uniform
+    const bool consumer = wave < 4;
+    const int wm = (wave & 3) >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * WS_BM, n0 = blockIdx.y * WS_BN;
+    const int stid = tid & 255;
+    const int akq = stid & 7, arow_ = stid >> 3;
+    const int bkg = stid & 3, brow_ = stid >> 2;
+
+    const int cin_steps = p.Cin / CBK;
+    const int wkd = p.transposed ? 1 : p.kd, wkh = p.transposed ? 1 : p.kh, wkw = p.transposed ? 1 : p.kw;
+    const int taps = wkd * wkh * wkw;
+    const int n_iters_all = taps * cin_steps;
+    int it_begin = 0, it_end = n_iters_all;
+    int ztap = 0;
+    if (p.transposed) {
+        ztap = blockIdx.z;
+    } else if (p.splits > 1) {
+        const int s = blockIdx.z;
+        it_begin = (int)((int64_t)n_iters_all * s / p.splits);
+        it_end = (int)((int64_t)n_iters_all * (s + 1) / p.splits);
+    }
+    const int n_it = it_end - it_begin;
+    const int n_round = (n_it + WS_DEPTH - 1) / WS_DEPTH * WS_DEPTH;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (!consumer) {
+        // ---------------- producers ----------------
+        // A: buffer base shifted back by the padding so that the tap offset in the scalar register is non-negative
+        const int64_t shift = p.transposed ? 0 : (((int64_t)p.pd * p.H + p.ph) * p.W + p.pw) * p.Cin;
+        const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in - shift), 0, WS_OOB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc((void*)wsplit, 0, WS_OOB, 0x00020000);
+        unsigned avoff[AR], amask[AR];   // byte offset of the row's own position; bit t = tap t reads inside the grid
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int m = m0 + arow_ + 32 * i;
+            const bool vok = m < p.M;
+            const int mm = vok ? m : 0;
+            const int ow_ = p.transposed ? p.W : p.OW, oh_ = p.transposed ? p.H : p.OH;
+            const int vw = mm % ow_, vh = (mm / ow_) % oh_, vd = mm / (ow_ * oh_);
+            const int sd = p.transposed ? 1 : p.sd, sh = p.transposed ? 1 : p.sh, sw = p.transposed ? 1 : p.sw;
+            avoff[i] = (unsigned)(((((int64_t)vd * sd) * p.H + vh * sh) * p.W + vw * sw) * p.Cin * 4 + akq * 16);
+            unsigned msk = 0;
+            if (vok) {
+                if (p.transposed) {
+                    msk = 1u;
+                } else {
+                    for (int t = 0; t < taps; ++t) {
+                        const int kd = t / (wkh * wkw), kh = (t / wkw) % wkh, kw = t % wkw;
+                        const int id = vd * sd + kd - p.pd, ih = vh * sh + kh - p.ph, iw = vw * sw + kw - p.pw;
+                        if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) msk |= 1u << t;
+                    }
+                }
+            }
+            amask[i] = msk;
+        }
+        unsigned bvoff[BR];
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int co = n0 + brow_ + 64 * i;
+            bvoff[i] = co < p.Cout ? (unsigned)((co * CBK + bkg * 8) * 2) : WS_OOB;
+        }
+        const unsigned wtile_b = (unsigned)p.Cout * CBK * 2;   // bytes of one weight plane of one K step
+        // LDS destinations (bytes within a stage): the chunk swizzle depends on the row only through (row >> 2) & 3
+        unsigned adst[AR], bdst[BR];
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int row = arow_ + 32 * i;
+            adst[i] = (unsigned)((row * CBK + (((akq >> 1) ^ ((row >> 2) & 3)) * 8) + (akq & 1) * 4) * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int row = brow_ + 64 * i;
+            bdst[i] = (unsigned)((3 * APL + row * CBK + ((bkg ^ ((row >> 2) & 3)) * 8)) * 2);
+        }
+
+        int nkd, nkh, nkw, ncs;   // the next tile to load: chunk outermost, taps innermost
+        {
+            const int t0 = it_begin % taps;
+            ncs = it_begin / taps;
+            nkd = t0 / (wkh * wkw); nkh = (t0 / wkw) % wkh; nkw = t0 % wkw;
+        }
+        u32x4 ra[WS_DEPTH][AR], rb[WS_DEPTH][BR][3];
+        auto load_tile = [&](int slot, bool live) {
+            const int tapw = (nkd * wkh + nkh) * wkw + nkw;                    // tap inside the walk (mask bit)
+            const int tap = p.transposed ? ztap : tapw;                        // tap inside the weights
+            // scalar offsets (readfirstlane: the buffer instruction takes them from an SGPR, no waterfall loop)
+            const unsigned asoff = __builtin_amdgcn_readfirstlane((unsigned)(((((int64_t)nkd * p.H + nkh) * p.W + nkw) * p.Cin + ncs * CBK) * 4));
+            const unsigned bsoff = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)tap * cin_steps + ncs) * 3) * wtile_b);
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const bool ok = live && ((amask[i] >> tapw) & 1u);
+                ra[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(ares, ok ? avoff[i] : WS_OOB, asoff, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    rb[slot][i][pl] = __builtin_amdgcn_raw_buffer_load_b128(bres, live ? bvoff[i] : WS_OOB, __builtin_amdgcn_readfirstlane(bsoff + pl * wtile_b), 0);
+            if (++nkw == wkw) {
+                nkw = 0;
+                if (++nkh == wkh) {
+                    nkh = 0;
+                    if (++nkd == wkd) { nkd = 0; ++ncs; }
+                }
+            }
+        };
+        auto store_tile = [&](int slot, int stage) {
+            char* base = reinterpret_cast<char*>(lds16) + stage * (STAGE * 2);
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const u32x4 u = ra[slot][i];
+                uint2 s0, s1, s2;
+                spl_split4(make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)), s0, s1, s2);
+                *reinterpret_cast<uint2*>(base + adst[i]) = s0;
+                *reinterpret_cast<uint2*>(base + adst[i] + APL * 2) = s1;
+                *reinterpret_cast<uint2*>(base + adst[i] + APL * 4) = s2;
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(base + bdst[i] + pl * (BPL * 2)) = rb[slot][i][pl];
+        };
+
+#pragma unroll
+        for (int d = 0; d < WS_DEPTH; ++d) load_tile(d, d < n_it);
+        store_tile(0, 0);
+        load_tile(0, WS_DEPTH < n_it);
+        __syncthreads();
+        for (int j0 = 0; j0 < n_round; j0 += WS_DEPTH) {
+#pragma unroll
+            for (int d = 0; d < WS_DEPTH; ++d) {   // tile j0 + d is being multiplied; stage tile j0 + d + 1 (ring slot (d + 1) % DEPTH)
+                store_tile((d + 1) % WS_DEPTH, (j0 + d + 1) & 1);
+                load_tile((d + 1) % WS_DEPTH, j0 + d + 1 + WS_DEPTH < n_it);
+                __syncthreads();
+            }
+        }
+    } else {
+        // ---------------- consumers ----------------
+        const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 2) & 3;
+        const int aoff = (wm * 64 + frow) * CBK;
+        const int boff = 3 * APL + (wn * 128 + frow) * CBK;
+        const int kc0 = ((0 + fh) ^ fsw) * 8, kc1 = ((2 + fh) ^ fsw) * 8;   // swizzled chunk of the two 16-k sub-steps
+        __syncthreads();
+        for (int j = 0; j < n_round; ++j) {
+            if (j < n_it) {
+                const uint16_t* st = lds16 + (j & 1) * STAGE;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int kc = ks == 0 ? kc0 : kc1;
+                    bf16x8 fa[3][2], fb[3][4];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) fa[pl][t] = *reinterpret_cast<const bf16x8*>(st + aoff + pl * APL + t * 32 * CBK + kc);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) fb[pl][t] = *reinterpret_cast<const bf16x8*>(st + boff + pl * BPL + t * 32 * CBK + kc);
+                    }
+#pragma unroll
+                    for (int order = 2; order >= 0; --order)
+#pragma unroll
+                        for (int pa = 0; pa <= order; ++pa) {
+                            const int pb = order - pa;
+#pragma unroll
+                            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                                for (int tb = 0; tb < 4; ++tb)
+                                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][ta], fb[pb][tb], acc[ta][tb], 0, 0, 0);
+                        }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (all 8 waves store): one 64-row half of the tile at a time through LDS ----
+    constexpr int CLDC = WS_BN + 4;
+    float* Cs = reinterpret_cast<float*>(lds16);
+    for (int h = 0; h < 2; ++h) {
+        if (consumer && wm == h) {
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        Cs[(ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CLDC + wn * 128 + tb * 32 + (lane & 31)] = acc[ta][tb][r];
+        }
+        __syncthreads();
+        conv_store_rows<WS_BN, 512>(p, Cs, CLDC, m0 + h * 64, 64, n0, tid, ztap, blockIdx.z);
+        __syncthreads();
+    }
+}
+
+static int split_launch_ws(const Conv3dParams& p, hipStream_t st, const char* fn) {
+    const int taps = p.transposed ? 1 : p.kd * p.kh * p.kw;
+    NDET_REQUIRE(taps <= 32, NDET_E_UNSUPPORTED, "%s: the 128x256 tile supports at most 32 taps", fn);
+    NDET_REQUIRE((int64_t)p.D * p.H * p.W * p.Cin * 4 < ((int64_t)1 << 31) && (int64_t)(p.transposed ? 8 : taps) * p.Cin * p.Cout * 6 < ((int64_t)1 << 31),
+                 NDET_E_UNSUPPORTED, "%s: the 128x256 tile addresses at most 2 GB per operand", fn);
+    const int zdim = p.transposed ? 8 : p.splits;
+    dim3 grid((p.M + WS_BM - 1) / WS_BM, (p.Cout + WS_BN - 1) / WS_BN, zdim);
+    const size_t lds = (size_t)2 * 3 * (WS_BM + WS_BN) * CBK * sizeof(uint16_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_conv_split_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_conv_split_ws, grid, dim3(512), lds, st, p, (const uint16_t*)p.w);
+    return NDET_OK;
+}
+
 template <int BM, int BN, int WGM, int WGN>
 static int split_launch_tile(const Conv3dParams& p, hipStream_t st, const char* fn) {
     const int zdim = p.transposed ? 8 : p.splits;
@@ -245,8 +497,7 @@ static int split_launch_tile(const Conv3dParams& p, hipStream_t st, const char* 
             attr_set = true;
         }
     }
-    const int64_t plane = (int64_t)(p.transposed ? 8 : p.kd * p.kh * p.kw) * p.Cout * p.Cin;
-    hipLaunchKernelGGL((k_conv_split<BM, BN, WGM, WGN>), grid, dim3(64 * WGM * WGN), lds, st, p, (const uint16_t*)p.w, plane);
+    hipLaunchKernelGGL((k_conv_split<BM, BN, WGM, WGN>), grid, dim3(64 * WGM * WGN), lds, st, p, (const uint16_t*)p.w);
     return NDET_OK;
 }
 
@@ -258,6 +509,7 @@ int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn)
         case 64: rc = split_launch_tile<64, 64, 2, 2>(p, st, fn); break;
         case 128: rc = split_launch_tile<128, 128, 2, 2>(p, st, fn); break;
         case 12864: rc = split_launch_tile<128, 64, 2, 2>(p, st, fn); break;
+        case 128256: rc = split_launch_ws(p, st, fn); break;
         default: ndet_set_error("%s: unknown tile %d", fn, tile); return NDET_E_INVALID;
     }
     if (rc != NDET_OK) return rc;
@@ -265,29 +517,32 @@ int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn)
     return conv_splitk_reduce_launch(p, st, fn);
 }
 
-// fp32 array -> three bf16 planes (plane stride n): x = p0 + p1 + p2 exactly
-__global__ __launch_bounds__(256) void k_split_bf16x3(const float* __restrict__ x, int64_t n, uint16_t* __restrict__ planes) {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+// packed fp32 weights (taps, Cout, Cin) -> three bf16 planes tiled per K step, (taps, Cin/32, 3, Cout, 32):
+// w = p0 + p1 + p2 exactly
+__global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ w, int taps, int Cout, int Cin, uint16_t* __restrict__ out) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;   // element pair along Cin
+    const int64_t n = (int64_t)taps * Cout * Cin;
     if (i >= n) return;
-    const float a = x[i], b = (i + 1 < n) ? x[i + 1] : 0.f;
+    const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), tap = (int)(i / ((int64_t)Cin * Cout));
+    const float a = w[i], b = w[i + 1];
     const uint32_t o0 = spl_pack(a, b);
     const float ra = a - spl_lo(o0), rb = b - spl_hi(o0);
     const uint32_t o1 = spl_pack(ra, rb);
     const uint32_t o2 = spl_pack(ra - spl_lo(o1), rb - spl_hi(o1));
     const uint32_t o[3] = {o0, o1, o2};
+    const int steps = Cin / CBK;
+    uint16_t* dst = out + (((int64_t)tap * steps + ci / CBK) * 3 * Cout + co) * CBK + (ci % CBK);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-        planes[pl * n + i] = (uint16_t)(o[pl] & 0xffffu);
-        if (i + 1 < n) planes[pl * n + i + 1] = (uint16_t)(o[pl] >> 16);
-    }
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint32_t*>(dst + (int64_t)pl * Cout * CBK) = o[pl];
 }
 
-extern "C" int ndet_split_bf16x3(const float* x, int64_t n, uint16_t* planes, void* stream) {
-    const char* fn = "ndet_split_bf16x3";
-    NDET_REQUIRE(x && planes, NDET_E_INVALID, "%s: null pointer", fn);
-    NDET_REQUIRE(n > 0, NDET_E_INVALID, "%s: n must be positive", fn);
-    const int64_t work = (n + 1) / 2;
-    hipLaunchKernelGGL(k_split_bf16x3, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, planes);
+extern "C" int ndet_split_weights_bf16x3(const float* w_packed, int taps, int Cout, int Cin, uint16_t* planes, void* stream) {
+    const char* fn = "ndet_split_weights_bf16x3";
+    NDET_REQUIRE(w_packed && planes, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(taps > 0 && Cout > 0 && Cin > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
+    NDET_REQUIRE(Cin % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
+    const int64_t work = (int64_t)taps * Cout * Cin / 2;
+    hipLaunchKernelGGL(k_split_weights, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_packed, taps, Cout, Cin, planes);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
@@ -300,7 +555,7 @@ extern "C" int ndet_conv_ndhwc_split(const float* in, const uint16_t* w_planes, 
     NDET_REQUIRE(in && w_planes && out && kernel && stride && pad, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
     NDET_REQUIRE((scale == nullptr) == (shift == nullptr), NDET_E_INVALID, "%s: scale and shift go together", fn);
-    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128 || tile == 12864), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
+    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128 || tile == 12864 || tile == 128256), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
     NDET_REQUIRE(Cin % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
     NDET_REQUIRE((((uintptr_t)in | (uintptr_t)w_planes) & 15) == 0, NDET_E_UNSUPPORTED, "%s: in / weights must be 16-byte aligned", fn);
     Conv3dParams p;

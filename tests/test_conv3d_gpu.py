@@ -175,7 +175,7 @@ def test_conv2d_nhwc_matches_torch_fp32(device, arith, cin, cout, nhw, k, stride
     assert float((got.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("tile", [64, 128, 12864])
+@pytest.mark.parametrize("tile", [64, 128, 12864, 128256])
 def test_split_conv_is_fp32_accurate_against_fp64(device, tile):
     """The 3-term bf16 split keeps fp32 accuracy: against an fp64 convolution its error is at the level of the
     fp32-MFMA kernel's (and of the CPU fp32 convolution), orders below a plain bf16 product (~4e-3)."""
@@ -200,12 +200,48 @@ def test_split_conv_is_fp32_accurate_against_fp64(device, tile):
     assert e_split <= 2.0 * max(e_f32, e_cpu) and e_split < 1e-4, (e_split, e_f32, e_cpu)
 
 
+WS_CASES = [
+    # cin, cout, grid, k, stride, transposed, relu, residual, splits   (wave-specialised 128 x 256 tile of the bf16x3 kernel)
+    (64, 256, (9, 8, 6), 3, 1, False, 1, True, 1),      # M = 432: ragged last M tile, padding taps everywhere
+    (96, 300, (7, 6, 5), 3, 2, False, 0, False, 1),     # Cout past one N tile and not a tile multiple, stride 2
+    (128, 256, (6, 6, 4), 3, 1, False, 2, True, 3),     # split-K + ReLU before the residual
+    (64, 512, (5, 4, 3), 2, 2, True, 1, False, 1),      # transposed k2 s2
+    (256, 25, (10, 10, 4), 3, 1, False, 0, False, 2),   # Cout < 4-aligned (scalar column epilogue)
+    (32, 256, (3, 12, 16), 1, 1, False, 1, False, 1),   # 1x1x1, a single K step
+]
+
+
+@pytest.mark.parametrize("cin,cout,grid,k,stride,tr,relu,use_res,splits", WS_CASES)
+def test_split_conv_wave_specialised_tile(device, cin, cout, grid, k, stride, tr, relu, use_res, splits):
+    from nerfdet_amd import conv3d
+    torch.manual_seed(cin + cout + k)
+    conv = nn.ConvTranspose3d(cin, cout, 2, 2, bias=False) if tr else nn.Conv3d(cin, cout, k, stride, k // 2, bias=False)
+    bn = nn.BatchNorm3d(cout).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+    x = torch.randn(*grid, cin)
+    with torch.no_grad():
+        probe = _ref(x, conv, bn)
+        res = torch.randn_like(probe) if use_res else None
+        ref = _ref(x, conv, bn, res, relu)
+        pk = conv3d.packed([conv.to(device)], bn.to(device))
+        prev = conv3d.set_arithmetic("bf16x3")
+        try:
+            got = conv3d.conv3d_ndhwc(x.to(device), pk, residual=None if res is None else res.to(device), relu=relu, splits=splits, tile=128256)
+        finally:
+            conv3d.set_arithmetic(prev)
+    assert got.shape == ref.shape
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got.cpu() - ref).abs().max()) <= 2e-5 * scale
+
+
 def test_split_planes_sum_exactly(device):
     from nerfdet_amd import conv3d
     torch.manual_seed(6)
-    w = (torch.randn(1, 37, 64) * torch.logspace(-20, 20, 64)).to(device)
-    planes = conv3d.split_planes(dict(w=w)).view(torch.bfloat16).double()
-    assert torch.equal(planes.sum(0), w.double())
+    w = (torch.randn(3, 37, 64) * torch.logspace(-20, 20, 64)).to(device)
+    planes = conv3d.split_planes(dict(w=w)).view(torch.bfloat16).double()   # (taps, Cin/32, 3, Cout, 32)
+    back = planes.sum(2).permute(0, 2, 1, 3).reshape(3, 37, 64)
+    assert torch.equal(back, w.double())
 
 
 def test_resnet_fpn_hip_matches_library(device):

@@ -23,6 +23,11 @@ LAYERS = [  # name, cin, cout, (n,h,w), k, stride, residual
 ]
 
 def main():
+    from nerfdet_amd import conv3d as C3
+    if len(sys.argv) > 1:
+        C3.set_arithmetic(sys.argv[1])
+    tiles = (64, 128, 12864) if C3.ARITHMETIC == "bf16x3" else (64, 128)
+    print("arithmetic", C3.ARITHMETIC, flush=True)
     dev = torch.device("cuda")
     tot_best = tot_auto = 0.0
     for name, cin, cout, nhw, k, s, use_res in LAYERS:
@@ -42,7 +47,7 @@ def main():
                 e0.record(); conv2d_nhwc(x, pk, residual=res, relu=1, **kw); e1.record(); torch.cuda.synchronize()
                 if i >= 2: ts.append(e0.elapsed_time(e1))
             return sorted(ts)[2]
-        for tile, splits in itertools.product((64, 128), (1, 2, 3, 4, 8)):
+        for tile, splits in itertools.product(tiles, (1, 2, 3, 4, 8)):
             if splits > k * k * (cin // 32): continue
             t = run(tile=tile, splits=splits)
             if best is None or t < best[0]: best = (t, tile, splits)

@@ -23,6 +23,11 @@ LAYERS = [  # name, cin, cout, grid(in), k, stride, transposed
 ]
 
 def main():
+    from nerfdet_amd import conv3d as C3
+    if len(sys.argv) > 1:
+        C3.set_arithmetic(sys.argv[1])
+    tiles = (64, 128, 12864) if C3.ARITHMETIC == "bf16x3" else (64, 128)
+    print("arithmetic", C3.ARITHMETIC, flush=True)
     dev = torch.device("cuda")
     for name, cin, cout, grid, k, s, tr in LAYERS:
         conv = (nn.ConvTranspose3d(cin, cout, 2, 2, bias=False) if tr else nn.Conv3d(cin, cout, k, s, k // 2, bias=False)).to(dev)
@@ -32,7 +37,7 @@ def main():
         od = [2 * g for g in grid] if tr else [(g + 2 * (k // 2) - k) // s + 1 for g in grid]
         flops = 2 * od[0] * od[1] * od[2] * cout * cin * (1 if tr else k ** 3)
         best = None
-        for tile, splits in itertools.product((64, 128), (1,) if tr else (1, 2, 3, 4, 6, 8)):
+        for tile, splits in itertools.product(tiles, (1,) if tr else (1, 2, 3, 4, 6, 8)):
             if splits > k ** 3 * (cin // 32):
                 continue
             try:
