@@ -95,6 +95,8 @@ def split_planes(pk: dict) -> torch.Tensor:
     if planes is None:
         w = pk["w"]
         taps, cout, cin = w.shape
+        if cin % 32:
+            raise ValueError(f"conv_ndhwc_split: Cin={cin} must be a multiple of 32")
         planes = torch.empty((taps, cin // 32, 3, cout, 32), dtype=torch.int16, device=w.device)
         st = c_void_p(torch.cuda.current_stream(w.device).cuda_stream)
         check(_lib.load().ndet_split_weights_bf16x3(_ptr(w), taps, cout, cin, _ptr(planes), st), "split_weights_bf16x3")
