@@ -394,6 +394,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
                 for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(base + bdst[i] + pl * (BPL * 2)) = rb[slot][i][pl];
         };
 
+        __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int d = 0; d < WS_DEPTH; ++d) load_tile(d, d < n_it);
         store_tile(0, 0);
