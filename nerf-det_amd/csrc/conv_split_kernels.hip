@@ -251,6 +251,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
 // spreads the 16 lanes of every ds_read_b128 group over all 16 slots of the 256-byte bank row.
 // ------------------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// chunk swizzle of the unpadded 64-byte LDS rows: physical 16-byte chunk = chunk ^ ws_swz(row).  The 16 x 16 x 32 fragment
+// read (lane l: row l & 15, chunk l >> 4) is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... -- rows
+// {0-3,12-15} at chunk c together with rows 4-11 at chunk c ^ 1; the table [0,2,3,1] over (row >> 2) & 3 puts those 16
+// accesses on 16 distinct slots of the 256-byte bank row.
+__device__ __forceinline__ int ws_swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // [0,2,3,1]
 #define WS_BM 128
 #define WS_BN 256
 #define WS_DEPTH 2
@@ -288,13 +294,11 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
     const int n_it = it_end - it_begin;
     const int n_round = (n_it + WS_DEPTH - 1) / WS_DEPTH * WS_DEPTH;
 
-    f32x16 acc[2][4];
+    f32x4v acc[4][8];   // 16 x 16 tiles of the wave's 64 x 128
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4v){0.f, 0.f, 0.f, 0.f};
 
     if (!consumer) {
         // ---------------- producers ----------------
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
         const int64_t shift = p.transposed ? 0 : (((int64_t)p.pd * p.H + p.ph) * p.W + p.pw) * p.Cin;
         const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in - shift), 0, WS_OOB, 0x00020000);
         const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc((void*)wsplit, 0, WS_OOB, 0x00020000);
-        unsigned avoff[AR], amask[AR];   // byte offset of the row's own position; bit t = tap t reads inside the grid
+        unsigned avoff[AR], amask[AR];   // byte offset of the row's own position; bit t CLEAR = tap t reads inside the grid
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int m = m0 + arow_ + 32 * i;
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
                     }
                 }
             }
-            amask[i] = msk;
+            amask[i] = ~msk;
         }
         unsigned bvoff[BR];
 #pragma unroll
@@ -338,12 +342,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int row = arow_ + 32 * i;
-            adst[i] = (unsigned)((row * CBK + (((akq >> 1) ^ ((row >> 2) & 3)) * 8) + (akq & 1) * 4) * 2);
+            adst[i] = (unsigned)((row * CBK + (((akq >> 1) ^ ws_swz(row)) * 8) + (akq & 1) * 4) * 2);
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
             const int row = brow_ + 64 * i;
-            bdst[i] = (unsigned)((3 * APL + row * CBK + ((bkg ^ ((row >> 2) & 3)) * 8)) * 2);
+            bdst[i] = (unsigned)((3 * APL + row * CBK + ((bkg ^ ws_swz(row)) * 8)) * 2);
         }
 
         int nkd, nkh, nkw, ncs;   // the next tile to load: chunk outermost, taps innermost
@@ -353,22 +357,26 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
             nkd = t0 / (wkh * wkw); nkh = (t0 / wkw) % wkh; nkw = t0 % wkw;
         }
         u32x4 ra[WS_DEPTH][AR], rb[WS_DEPTH][BR][3];
+        unsigned asoff = 0, bsoff = 0, tapsh = 31;
         auto load_tile = [&](int slot, bool live) {
-            const int tapw = (nkd * wkh + nkh) * wkw + nkw;                    // tap inside the walk (mask bit)
-            const int tap = p.transposed ? ztap : tapw;                        // tap inside the weights
-            // scalar offsets (readfirstlane: the buffer instruction takes them from an SGPR, no waterfall loop)
-            const unsigned asoff = __builtin_amdgcn_readfirstlane((unsigned)(((((int64_t)nkd * p.H + nkh) * p.W + nkw) * p.Cin + ncs * CBK) * 4));
-            const unsigned bsoff = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)tap * cin_steps + ncs) * 3) * wtile_b);
-#pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                const bool ok = live && ((amask[i] >> tapw) & 1u);
-                ra[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(ares, ok ? avoff[i] : WS_OOB, asoff, 0);
+            // scalar side of the addresses (the buffer instruction takes them from SGPRs).  A tile past the end of this
+            // workgroup's K range (`live` false: the last WS_DEPTH steps) re-reads the previous tile -- legal addresses, the
+            // copy is staged but never multiplied -- so no per-load select is needed
+            if (live) {
+                const int tapw = (nkd * wkh + nkh) * wkw + nkw;                    // tap inside the walk (mask bit)
+                const int tap = p.transposed ? ztap : tapw;                        // tap inside the weights
+                asoff = __builtin_amdgcn_readfirstlane((unsigned)(((((int64_t)nkd * p.H + nkh) * p.W + nkw) * p.Cin + ncs * CBK) * 4));
+                bsoff = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)tap * cin_steps + ncs) * 3) * wtile_b);
+                tapsh = 31 - tapw;
             }
+#pragma unroll
+            for (int i = 0; i < AR; ++i)   // (amask << (31 - tap)) has bit 31 set when this tap reads padding: offset >= 2^31 -> zeros
+                ra[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(ares, ((amask[i] << tapsh) & WS_OOB) | avoff[i], asoff, 0);
 #pragma unroll
             for (int i = 0; i < BR; ++i)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    rb[slot][i][pl] = __builtin_amdgcn_raw_buffer_load_b128(bres, live ? bvoff[i] : WS_OOB, __builtin_amdgcn_readfirstlane(bsoff + pl * wtile_b), 0);
+                    rb[slot][i][pl] = __builtin_amdgcn_raw_buffer_load_b128(bres, bvoff[i], __builtin_amdgcn_readfirstlane(bsoff + pl * wtile_b), 0);
             if (++nkw == wkw) {
                 nkw = 0;
                 if (++nkh == wkh) {
@@ -410,37 +418,36 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
         }
     } else {
         // ---------------- consumers ----------------
-        const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 2) & 3;
-        const int aoff = (wm * 64 + frow) * CBK;
-        const int boff = 3 * APL + (wn * 128 + frow) * CBK;
-        const int kc0 = ((0 + fh) ^ fsw) * 8, kc1 = ((2 + fh) ^ fsw) * 8;   // swizzled chunk of the two 16-k sub-steps
+        // v_mfma_f32_16x16x32_bf16: lane l holds row (l & 15), k = 8 (l >> 4) + j -> one 16-byte read covers a K step's
+        // quarter row; twice the MFMA count of the 32x32x16 form at half the cycles each (more issue gaps for the
+        // producer wave on the same SIMD, and the chip holds a higher clock on this shape)
+        const int frow = lane & 15, fc = lane >> 4;
+        const int kc = (fc ^ ws_swz(frow)) * 8;                 // (row >> 2) & 3 is the same for every 16-row tile
+        const int aoff = (wm * 64 + frow) * CBK + kc;
+        const int boff = 3 * APL + (wn * 128 + frow) * CBK + kc;
         __syncthreads();
         for (int j = 0; j < n_round; ++j) {
             if (j < n_it) {
                 const uint16_t* st = lds16 + (j & 1) * STAGE;
+                bf16x8 fa[3][4], fb[3][8];
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int kc = ks == 0 ? kc0 : kc1;
-                    bf16x8 fa[3][2], fb[3][4];
+                for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
+                    for (int t = 0; t < 4; ++t) fa[pl][t] = *reinterpret_cast<const bf16x8*>(st + aoff + pl * APL + t * 16 * CBK);
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) fa[pl][t] = *reinterpret_cast<const bf16x8*>(st + aoff + pl * APL + t * 32 * CBK + kc);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) fb[pl][t] = *reinterpret_cast<const bf16x8*>(st + boff + pl * BPL + t * 32 * CBK + kc);
-                    }
-#pragma unroll
-                    for (int order = 2; order >= 0; --order)
-#pragma unroll
-                        for (int pa = 0; pa <= order; ++pa) {
-                            const int pb = order - pa;
-#pragma unroll
-                            for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-                                for (int tb = 0; tb < 4; ++tb)
-                                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][ta], fb[pb][tb], acc[ta][tb], 0, 0, 0);
-                        }
+                    for (int t = 0; t < 8; ++t) fb[pl][t] = *reinterpret_cast<const bf16x8*>(st + boff + pl * BPL + t * 16 * CBK);
                 }
+#pragma unroll
+                for (int order = 2; order >= 0; --order)
+#pragma unroll
+                    for (int pa = 0; pa <= order; ++pa) {
+                        const int pb = order - pa;
+#pragma unroll
+                        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                            for (int tb = 0; tb < 8; ++tb)
+                                acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pa][ta], fb[pb][tb], acc[ta][tb], 0, 0, 0);
+                    }
             }
             __syncthreads();
         }
@@ -451,13 +458,14 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
     float* Cs = reinterpret_cast<float*>(lds16);
     for (int h = 0; h < 2; ++h) {
         if (consumer && wm == h) {
+            // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-            for (int ta = 0; ta < 2; ++ta)
+            for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-                for (int tb = 0; tb < 4; ++tb)
+                for (int tb = 0; tb < 8; ++tb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        Cs[(ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CLDC + wn * 128 + tb * 32 + (lane & 31)] = acc[ta][tb][r];
+                    for (int r = 0; r < 4; ++r)
+                        Cs[(ta * 16 + (lane >> 4) * 4 + r) * CLDC + wn * 128 + tb * 16 + (lane & 15)] = acc[ta][tb][r];
         }
         __syncthreads();
         conv_store_rows<WS_BN, 512>(p, Cs, CLDC, m0 + h * 64, 64, n0, tid, ztap, blockIdx.z);

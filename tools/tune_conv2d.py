@@ -47,7 +47,7 @@ def main():
                 e0.record(); conv2d_nhwc(x, pk, residual=res, relu=1, **kw); e1.record(); torch.cuda.synchronize()
                 if i >= 2: ts.append(e0.elapsed_time(e1))
             return sorted(ts)[2]
-        for tile, splits in itertools.product(tiles, (1, 2, 3, 4, 8)):
+        for tile, splits in itertools.product(tiles, (1, 2, 3, 4, 8, 16)):
             if splits > k * k * (cin // 32): continue
             t = run(tile=tile, splits=splits)
             if best is None or t < best[0]: best = (t, tile, splits)

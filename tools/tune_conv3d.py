@@ -37,7 +37,7 @@ def main():
         od = [2 * g for g in grid] if tr else [(g + 2 * (k // 2) - k) // s + 1 for g in grid]
         flops = 2 * od[0] * od[1] * od[2] * cout * cin * (1 if tr else k ** 3)
         best = None
-        for tile, splits in itertools.product(tiles, (1,) if tr else (1, 2, 3, 4, 6, 8)):
+        for tile, splits in itertools.product(tiles, (1,) if tr else (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)):
             if splits > k ** 3 * (cin // 32):
                 continue
             try:
