@@ -83,7 +83,7 @@ def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: 
         tm, tn = {12864: (128, 64), 128256: (128, 256)}.get(tile, (tile, tile))
         tiles = ((m + tm - 1) // tm) * ((cout + tn - 1) // tn)
         splits = 1
-        while splits < 8 and k_iters // (splits + 1) >= 32 and tiles * (splits + 1) <= 1024:
+        while splits < 32 and k_iters // (splits + 1) >= 24 and tiles * (splits + 1) <= 768:
             splits += 1
     return tile, splits
 
