@@ -63,7 +63,7 @@ def choose_tiling(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 
 
 
 def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 0, transposed: bool = False):
-    """Tile (64 = 64x64, 128 = 128x128, 12864 = 128 rows x 64 channels, 128256 = wave-specialised 128 rows x 256 channels)
+    """Tile (64 = 64x64, 128 = 128x128, 12864 = 128 rows x 64 channels, 128256 = wave-specialised 128 rows x 256 channels, 3128 / 3256 = halo-stationary 128-voxel patch x 128 / 256 channels)
     and split-K factor for the bf16x3 kernel."""
     if tile == 0 and splits == 0:
         hit = TUNED_SPLIT.get((m, cout, k_iters, int(transposed)))
@@ -80,7 +80,7 @@ def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: 
     if splits == 0:
         if transposed:
             return tile, 1
-        tm, tn = {12864: (128, 64), 128256: (128, 256)}.get(tile, (tile, tile))
+        tm, tn = {12864: (128, 64), 128256: (128, 256), 3128: (128, 128), 3256: (128, 256)}.get(tile, (tile, tile))
         tiles = ((m + tm - 1) // tm) * ((cout + tn - 1) // tn)
         splits = 1
         while splits < 32 and k_iters // (splits + 1) >= 24 and tiles * (splits + 1) <= 768:
@@ -106,6 +106,8 @@ def split_planes(pk: dict) -> torch.Tensor:
 
 def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, residual_up2, relu, splits, tile, m, k_iters, flops):
     tile, splits = choose_tiling_split(m, pk["cout"], k_iters, tile, 1 if (transposed or residual_up2) else splits, transposed)
+    if tile in (3128, 3256):   # halo-stationary tiles split K over the 32-channel chunks only
+        splits = min(splits, pk["cin"] // 32)
     ws = torch.empty((m * pk["cout"] * splits * 4,), dtype=torch.uint8, device=x.device) if splits > 1 else None
     i3 = lambda v: (ctypes.c_int * 3)(*v)
     st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)

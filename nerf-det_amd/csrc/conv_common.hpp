@@ -42,9 +42,14 @@ __device__ __forceinline__ int64_t conv_out_row(const Conv3dParams& p, int m, in
 // Fused epilogue over `rows` rows of a C tile staged in LDS (row stride cld floats, BN columns): per-channel scale/shift,
 // ReLU before or after the residual add, residual (optionally a half-resolution map read nearest-upsampled), or raw
 // split-K partials.  Threads own float4 pieces along Cout so global traffic is whole rows.
-template <int BN, int NTHR>
-__device__ __forceinline__ void conv_store_rows(const Conv3dParams& p, const float* Cs, int cld, int m_first, int rows, int n0, int tid,
-                                                int ztap, int zsplit) {
+struct ConvLinearRows {
+    int first;
+    __device__ __forceinline__ int operator()(int row) const { return first + row; }
+};
+
+template <int BN, int NTHR, typename RowMap>
+__device__ __forceinline__ void conv_store_rows_mapped(const Conv3dParams& p, const float* Cs, int cld, int rows, int n0, int tid, int ztap,
+                                                       int zsplit, RowMap m_of) {
     const bool raw = (!p.transposed && p.splits > 1);
     float* dst = raw ? p.partial + (int64_t)zsplit * p.M * p.Cout : p.out;
     auto res_row = [&](int m, int64_t orow) -> int64_t {
@@ -56,8 +61,8 @@ __device__ __forceinline__ void conv_store_rows(const Conv3dParams& p, const flo
         constexpr int V = BN / 4;
         for (int idx = tid; idx < rows * V; idx += NTHR) {
             const int row = idx / V, c4 = idx % V;
-            const int m = m_first + row, co = n0 + c4 * 4;
-            if (m >= p.M || co >= p.Cout) continue;
+            const int m = m_of(row), co = n0 + c4 * 4;   // m < 0: the tile row has no output voxel
+            if (m < 0 || m >= p.M || co >= p.Cout) continue;
             const int64_t orow = conv_out_row(p, m, ztap);
             float4 v = *reinterpret_cast<const float4*>(Cs + row * cld + c4 * 4);
             if (!raw) {
@@ -77,8 +82,8 @@ __device__ __forceinline__ void conv_store_rows(const Conv3dParams& p, const flo
     } else {  // Cout not a multiple of 4 (the fused head conv, Cout = 25): scalar columns
         for (int idx = tid; idx < rows * BN; idx += NTHR) {
             const int row = idx / BN, c = idx % BN;
-            const int m = m_first + row, co = n0 + c;
-            if (m >= p.M || co >= p.Cout) continue;
+            const int m = m_of(row), co = n0 + c;
+            if (m < 0 || m >= p.M || co >= p.Cout) continue;
             const int64_t orow = conv_out_row(p, m, ztap);
             float v = Cs[row * cld + c];
             if (!raw) {
@@ -90,4 +95,11 @@ __device__ __forceinline__ void conv_store_rows(const Conv3dParams& p, const flo
             dst[orow * p.Cout + co] = v;
         }
     }
+}
+
+// tile rows are consecutive GEMM rows starting at m_first
+template <int BN, int NTHR>
+__device__ __forceinline__ void conv_store_rows(const Conv3dParams& p, const float* Cs, int cld, int m_first, int rows, int n0, int tid,
+                                                int ztap, int zsplit) {
+    conv_store_rows_mapped<BN, NTHR>(p, Cs, cld, rows, n0, tid, ztap, zsplit, ConvLinearRows{m_first});
 }

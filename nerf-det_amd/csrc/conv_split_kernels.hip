@@ -491,6 +491,298 @@ static int split_launch_ws(const Conv3dParams& p, hipStream_t st, const char* fn
     return NDET_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Halo-stationary tile for stride-1 "same" convolutions with more than one tap (3x3 of the backbone / FPN, 3x3x3 of the
+// neck).  A partner wave gets about one VALU issue slot per MFMA on its SIMD, and the activation split costs 4.5 VALU
+// instructions per element: splitting the A tile anew for every tap (the tiles above) makes the producers the limiter.
+// Here the output tile is a TD x TH x TW patch of 128 voxels; for each 32-channel chunk the producers load and split the
+// patch plus its halo ONCE ((TD+kd-1)(TH+kh-1)(TW+kw-1) rows, 1.4 - 2.8 x 128) and all taps multiply out of that LDS
+// image -- a tap is a constant row offset in the halo grid.  Per tap step the producers only move the weight tile:
+// LDS-DMA (buffer_load ... lds, no registers, no ds_write), 2 - 3 stages deep, waited with counted vmcnt.
+// Consumers: 4 waves (2 x 2), 16x16x32 MFMAs, wave tile 64 x (16 NT16).
+// ------------------------------------------------------------------------------------------------
+struct HaloGeom {
+    int ltd, lth, ltw;     // log2 of the patch extents (TD TH TW = 128)
+    int npd, nph, npw;     // patches per axis
+    int HH, HW, NH;        // halo extents along H and W, halo rows in total
+    int T;                 // taps
+};
+
+// 16 bytes per lane, global -> LDS without registers: lane l lands at lds_dst + 16 l (lds_dst wave-uniform); lanes whose
+// offset is out of range write zeros.  (A plain function: the address-space cast does not survive the host pass of a
+// kernel template.)
+__device__ __forceinline__ void spl_dma16(__amdgpu_buffer_rsrc_t rsrc, uint16_t* lds_dst, unsigned voffset, unsigned soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
+}
+
+// tile row -> GEMM row of the output voxel it holds (-1 outside the grid)
+struct HaloRowMap {
+    int first, ltw, lth, d0, h0, w0, OD, OH, OW;
+    __device__ __forceinline__ int operator()(int row) const {
+        const int r = first + row;
+        const int tw = r & ((1 << ltw) - 1), th = (r >> ltw) & ((1 << lth) - 1), td = r >> (ltw + lth);
+        const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
+        return (od < OD && oh < OH && ow < OW) ? (od * OH + oh) * OW + ow : -1;
+    }
+};
+
+template <int NT16>
+__global__ __launch_bounds__(512, 1) void k_conv_split_halo(const Conv3dParams p, const uint16_t* __restrict__ wsplit, const HaloGeom g) {
+    constexpr int BN = 32 * NT16;
+    constexpr int HALO_MAX = (NT16 == 4) ? 400 : 224;
+    constexpr int NSTAGE = (NT16 == 4) ? 3 : 2;
+    constexpr int NPIECE = (HALO_MAX * 8 + 255) / 256;
+    constexpr int APL = HALO_MAX * CBK, BPL = BN * CBK;   // one plane, elements
+    constexpr int BSTAGE = 3 * BPL;
+    constexpr int BR = BN / 64;                            // weight rows per producer thread and plane
+    constexpr int NB = 3 * BR;                             // LDS-DMA instructions per producer thread and K step
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
+    uint16_t* Bs = lds16 + 3 * APL;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    const int wm = (wave & 3) >> 1, wn = wave & 1;
+    const int n0 = blockIdx.y * BN;
+    const int TH = 1 << g.lth, TW = 1 << g.ltw;
+    int pb = blockIdx.x;
+    const int pwi = pb % g.npw; pb /= g.npw;
+    const int phi = pb % g.nph;
+    const int pdi = pb / g.nph;
+    const int d0 = pdi << g.ltd, h0 = phi << g.lth, w0 = pwi << g.ltw;
+
+    const int nch_all = p.Cin / CBK;
+    int cb = 0, ce = nch_all;
+    if (p.splits > 1) {
+        cb = (int)((int64_t)nch_all * blockIdx.z / p.splits);
+        ce = (int)((int64_t)nch_all * (blockIdx.z + 1) / p.splits);
+    }
+    const int nch = ce - cb;
+    const int T = g.T;
+    const int S = nch * T;
+
+    f32x4v acc[4][NT16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NT16; ++b) acc[a][b] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    if (!consumer) {
+        // ---------------- producers ----------------
+        const int stid = tid & 255;
+        const int pw4 = wave - 4;
+        const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, WS_OOB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc((void*)wsplit, 0, WS_OOB, 0x00020000);
+        unsigned avoff[NPIECE], adst[NPIECE];
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) {
+            const int idx = stid + 256 * i;
+            const int row = idx >> 3, q = idx & 7;
+            const int hw = row % g.HW, hh = (row / g.HW) % g.HH, hd = row / (g.HW * g.HH);
+            const int vd = d0 - p.pd + hd, vh = h0 - p.ph + hh, vw = w0 - p.pw + hw;
+            const bool ok = row < g.NH && (unsigned)vd < (unsigned)p.D && (unsigned)vh < (unsigned)p.H && (unsigned)vw < (unsigned)p.W;
+            avoff[i] = ok ? (unsigned)((((int64_t)vd * p.H + vh) * p.W + vw) * p.Cin * 4 + q * 16) : WS_OOB;
+            // rows past the halo are never read: their pieces are not stored (adst = ~0u)
+            adst[i] = row < g.NH ? (unsigned)((row * CBK + (((q >> 1) ^ ws_swz(row)) * 8) + (q & 1) * 4) * 2) : ~0u;
+        }
+        // weight tile by LDS-DMA: lane (row = stid >> 2 (+ 64 i), physical chunk = stid & 3) fetches logical chunk
+        // physical ^ swizzle(row) of its row; the LDS image is lane-linear (1 KB per wave instruction)
+        unsigned bvoff[BR];
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int row = (stid >> 2) + 64 * i, co = n0 + row;
+            bvoff[i] = co < p.Cout ? (unsigned)((co * CBK + (((stid & 3) ^ ws_swz(row)) * 8)) * 2) : WS_OOB;
+        }
+        const unsigned wtile_b = (unsigned)p.Cout * CBK * 2;
+        int dt = 0, dc = 0;   // tap and chunk (relative to cb) of the next weight tile to fetch
+        auto dma_b = [&](int u) {   // tile u -> stage u % NSTAGE
+            const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)dt * nch_all + cb + dc) * 3) * wtile_b);
+            uint16_t* stage = Bs + (u % NSTAGE) * BSTAGE;
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    uint16_t* dst = stage + pl * BPL + (64 * i + pw4 * 16) * CBK;   // wave-uniform; the hardware adds lane * 16 B
+                    spl_dma16(bres, dst, bvoff[i], __builtin_amdgcn_readfirstlane(soff + pl * wtile_b));
+                }
+            if (++dt == T) { dt = 0; ++dc; }
+        };
+        u32x4 ra[NPIECE];
+        auto load_a = [&](int c) {
+            const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((cb + c) * CBK * 4));
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(ares, avoff[i], soff, 0);
+        };
+        auto split_store_a = [&]() {
+            char* base = reinterpret_cast<char*>(lds16);
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i) {
+                const u32x4 u = ra[i];
+                uint2 s0, s1, s2;
+                spl_split4(make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)), s0, s1, s2);
+                if (adst[i] != ~0u) {
+                    *reinterpret_cast<uint2*>(base + adst[i]) = s0;
+                    *reinterpret_cast<uint2*>(base + adst[i] + APL * 2) = s1;
+                    *reinterpret_cast<uint2*>(base + adst[i] + APL * 4) = s2;
+                }
+            }
+        };
+
+        __builtin_amdgcn_s_setprio(3);
+        load_a(0);
+#pragma unroll
+        for (int u = 0; u < NSTAGE - 1; ++u)
+            if (u < S) dma_b(u);
+        split_store_a();
+        if (nch > 1) load_a(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weight tile 0 (and whatever else) has landed
+        __syncthreads();                                     // P0
+        int s = 0;
+        for (int ci = 0; ci < nch; ++ci) {
+            for (int t = 0; t < T; ++t, ++s) {
+                if (s + NSTAGE - 1 < S) {
+                    dma_b(s + NSTAGE - 1);
+                    // tile s + 1 must have landed before the barrier; the NSTAGE - 2 younger tiles may stay in flight
+                    // (completion is in order: right after a chunk boundary the next chunk's activation loads are younger
+                    // than tile s + 1 and may stay in flight too)
+                    if (NSTAGE == 3) {
+                        if (t == 0 && ci + 1 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB + NPIECE) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();                             // P1
+            }
+            if (ci + 1 < nch) {
+                split_store_a();                             // chunk ci + 1 (loaded during chunk ci); the consumers wait at P2
+                __syncthreads();                             // P2
+                if (ci + 2 < nch) load_a(ci + 2);
+            }
+        }
+    } else {
+        // ---------------- consumers ----------------
+        const int frow = lane & 15, fc = lane >> 4;
+        int hr0[4];
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta) {
+            const int r = wm * 64 + ta * 16 + frow;
+            const int tw = r & (TW - 1), th = (r >> g.ltw) & (TH - 1), td = r >> (g.ltw + g.lth);
+            hr0[ta] = (td * g.HH + th) * g.HW + tw;
+        }
+        const int boff = (wn * (16 * NT16) + frow) * CBK + ((fc ^ ws_swz(frow)) * 8);
+        const int wkh = p.kh, wkw = p.kw;
+        __syncthreads();                                     // P0
+        int s = 0;
+        for (int ci = 0; ci < nch; ++ci) {
+            int kd = 0, kh = 0, kw = 0;
+            for (int t = 0; t < T; ++t, ++s) {
+                const int tapoff = (kd * g.HH + kh) * g.HW + kw;
+                const uint16_t* bst = Bs + (s % NSTAGE) * BSTAGE + boff;
+                bf16x8 fa[3][4], fb[3][NT16];
+#pragma unroll
+                for (int ta = 0; ta < 4; ++ta) {
+                    const int hr = hr0[ta] + tapoff;
+                    const uint16_t* ap = lds16 + hr * CBK + ((fc ^ ws_swz(hr)) * 8);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) fa[pl][ta] = *reinterpret_cast<const bf16x8*>(ap + pl * APL);
+                }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int tb = 0; tb < NT16; ++tb) fb[pl][tb] = *reinterpret_cast<const bf16x8*>(bst + pl * BPL + tb * 16 * CBK);
+#pragma unroll
+                for (int order = 2; order >= 0; --order)
+#pragma unroll
+                    for (int pa = 0; pa <= order; ++pa) {
+                        const int pbb = order - pa;
+#pragma unroll
+                        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                            for (int tb = 0; tb < NT16; ++tb)
+                                acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pa][ta], fb[pbb][tb], acc[ta][tb], 0, 0, 0);
+                    }
+                if (++kw == wkw) {
+                    kw = 0;
+                    if (++kh == wkh) { kh = 0; ++kd; }
+                }
+                __syncthreads();                             // P1
+            }
+            if (ci + 1 < nch) __syncthreads();               // P2
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+
+    // ---- epilogue (all 8 waves store): one 64-row half of the patch at a time through LDS ----
+    constexpr int CLDC = BN + 4;
+    float* Cs = reinterpret_cast<float*>(lds16);
+    for (int h = 0; h < 2; ++h) {
+        if (consumer && wm == h) {
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < NT16; ++tb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Cs[(ta * 16 + (lane >> 4) * 4 + r) * CLDC + wn * (16 * NT16) + tb * 16 + (lane & 15)] = acc[ta][tb][r];
+        }
+        __syncthreads();
+        conv_store_rows_mapped<BN, 512>(p, Cs, CLDC, 64, n0, tid, 0, blockIdx.z, HaloRowMap{h * 64, g.ltw, g.lth, d0, h0, w0, p.OD, p.OH, p.OW});
+        __syncthreads();
+    }
+}
+
+// patch shape for the halo tile: the power-of-two TD x TH x TW = 128 with the least padded work (weighted by the halo it drags)
+static bool halo_geometry(const Conv3dParams& p, int halo_max, HaloGeom& g) {
+    double best = 1e30;
+    for (int ltd = 0; ltd <= 7; ++ltd)
+        for (int lth = 0; lth + ltd <= 7; ++lth) {
+            const int ltw = 7 - ltd - lth;
+            const int TD = 1 << ltd, TH = 1 << lth, TW = 1 << ltw;
+            const int HD = TD + p.kd - 1, HH = TH + p.kh - 1, HW = TW + p.kw - 1;
+            const int NH = HD * HH * HW;
+            if (NH > halo_max) continue;
+            const int npd = (p.OD + TD - 1) / TD, nph = (p.OH + TH - 1) / TH, npw = (p.OW + TW - 1) / TW;
+            const double waste = (double)npd * TD * nph * TH * npw * TW / ((double)p.OD * p.OH * p.OW);
+            const double cost = waste * (1.0 + 0.03 * NH / 128.0);
+            if (cost < best) {
+                best = cost;
+                g.ltd = ltd; g.lth = lth; g.ltw = ltw; g.npd = npd; g.nph = nph; g.npw = npw; g.HH = HH; g.HW = HW; g.NH = NH;
+            }
+        }
+    g.T = p.kd * p.kh * p.kw;
+    return best < 1e29;
+}
+
+template <int NT16>
+static int split_launch_halo(const Conv3dParams& p, hipStream_t st, const char* fn) {
+    constexpr int BN = 32 * NT16, HALO_MAX = (NT16 == 4) ? 400 : 224, NSTAGE = (NT16 == 4) ? 3 : 2;
+    NDET_REQUIRE(!p.transposed && p.sd == 1 && p.sh == 1 && p.sw == 1 && (p.kd & 1) && (p.kh & 1) && (p.kw & 1) && p.pd == p.kd / 2 &&
+                     p.ph == p.kh / 2 && p.pw == p.kw / 2,
+                 NDET_E_UNSUPPORTED, "%s: the halo tile needs a stride-1 same-padded convolution with odd kernel extents", fn);
+    NDET_REQUIRE((int64_t)p.D * p.H * p.W * p.Cin * 4 < ((int64_t)1 << 31) && (int64_t)p.kd * p.kh * p.kw * p.Cin * p.Cout * 6 < ((int64_t)1 << 31),
+                 NDET_E_UNSUPPORTED, "%s: the halo tile addresses at most 2 GB per operand", fn);
+    NDET_REQUIRE(p.splits <= p.Cin / CBK, NDET_E_INVALID, "%s: the halo tile splits K over the %d channel chunks only", fn, p.Cin / CBK);
+    HaloGeom g;
+    NDET_REQUIRE(halo_geometry(p, HALO_MAX, g), NDET_E_UNSUPPORTED, "%s: no patch shape fits the halo tile", fn);
+    dim3 grid(g.npd * g.nph * g.npw, (p.Cout + BN - 1) / BN, p.splits);
+    size_t lds = (size_t)(3 * HALO_MAX * CBK + NSTAGE * 3 * BN * CBK) * sizeof(uint16_t);
+    const size_t cs = (size_t)64 * (BN + 4) * sizeof(float);
+    if (cs > lds) lds = cs;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_conv_split_halo<NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_conv_split_halo<NT16>, grid, dim3(512), lds, st, p, (const uint16_t*)p.w, g);
+    return NDET_OK;
+}
+
 template <int BM, int BN, int WGM, int WGN>
 static int split_launch_tile(const Conv3dParams& p, hipStream_t st, const char* fn) {
     const int zdim = p.transposed ? 8 : p.splits;
@@ -519,6 +811,8 @@ int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn)
         case 128: rc = split_launch_tile<128, 128, 2, 2>(p, st, fn); break;
         case 12864: rc = split_launch_tile<128, 64, 2, 2>(p, st, fn); break;
         case 128256: rc = split_launch_ws(p, st, fn); break;
+        case 3128: rc = split_launch_halo<4>(p, st, fn); break;
+        case 3256: rc = split_launch_halo<8>(p, st, fn); break;
         default: ndet_set_error("%s: unknown tile %d", fn, tile); return NDET_E_INVALID;
     }
     if (rc != NDET_OK) return rc;
@@ -564,7 +858,7 @@ extern "C" int ndet_conv_ndhwc_split(const float* in, const uint16_t* w_planes, 
     NDET_REQUIRE(in && w_planes && out && kernel && stride && pad, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
     NDET_REQUIRE((scale == nullptr) == (shift == nullptr), NDET_E_INVALID, "%s: scale and shift go together", fn);
-    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128 || tile == 12864 || tile == 128256), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
+    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128 || tile == 12864 || tile == 128256 || tile == 3128 || tile == 3256), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
     NDET_REQUIRE(Cin % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
     NDET_REQUIRE((((uintptr_t)in | (uintptr_t)w_planes) & 15) == 0, NDET_E_UNSUPPORTED, "%s: in / weights must be 16-byte aligned", fn);
     Conv3dParams p;

@@ -235,6 +235,40 @@ def test_split_conv_wave_specialised_tile(device, cin, cout, grid, k, stride, tr
     assert float((got.cpu() - ref).abs().max()) <= 2e-5 * scale
 
 
+HALO_CASES = [
+    # cin, cout, grid (D,H,W), kernel (kd,kh,kw), relu, residual, splits, tile   (halo-stationary tiles of the bf16x3 kernel)
+    (64, 128, (8, 8, 8), (3, 3, 3), 1, True, 1, 3128),        # exact patches
+    (64, 160, (5, 7, 9), (3, 3, 3), 0, False, 1, 3128),       # ragged on every axis, Cout past one N tile
+    (96, 128, (6, 6, 4), (3, 3, 3), 2, True, 3, 3128),        # split-K over the 3 chunks + ReLU before the residual
+    (64, 256, (3, 12, 16), (1, 3, 3), 1, False, 1, 3256),     # 2D 3x3 over a batch of 3 maps, 256 channels
+    (128, 300, (2, 15, 20), (1, 3, 3), 1, True, 2, 3256),     # odd map size, Cout ragged, split-K
+    (64, 25, (10, 10, 4), (3, 3, 3), 0, False, 1, 3128),      # scalar-column epilogue
+    (32, 128, (4, 9, 5), (3, 1, 3), 1, False, 1, 3128),       # mixed kernel extents, a single chunk
+]
+
+
+@pytest.mark.parametrize("cin,cout,grid,kern,relu,use_res,splits,tile", HALO_CASES)
+def test_split_conv_halo_tile(device, cin, cout, grid, kern, relu, use_res, splits, tile):
+    from nerfdet_amd import conv3d
+    torch.manual_seed(cin + cout + sum(kern))
+    conv = nn.Conv3d(cin, cout, kern, 1, tuple(k // 2 for k in kern), bias=False)
+    bn = nn.BatchNorm3d(cout).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+    x = torch.randn(*grid, cin)
+    with torch.no_grad():
+        probe = _ref(x, conv, bn)
+        res = torch.randn_like(probe) if use_res else None
+        ref = _ref(x, conv, bn, res, relu)
+        pk = conv3d.packed([conv.to(device)], bn.to(device))
+        out = torch.empty(ref.shape, device=device)
+        got = conv3d._conv_split(x.to(device), pk, out, grid, kern, (1, 1, 1), tuple(k // 2 for k in kern), False,
+                                 None if res is None else res.to(device), False, relu, splits, tile, ref.shape[0] * ref.shape[1] * ref.shape[2],
+                                 kern[0] * kern[1] * kern[2] * (cin // 32), 0)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got.cpu() - ref).abs().max()) <= 2e-5 * scale
+
+
 def test_split_planes_sum_exactly(device):
     from nerfdet_amd import conv3d
     torch.manual_seed(6)
