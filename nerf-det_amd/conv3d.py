@@ -106,8 +106,11 @@ def split_planes(pk: dict) -> torch.Tensor:
 
 def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, residual_up2, relu, splits, tile, m, k_iters, flops):
     tile, splits = choose_tiling_split(m, pk["cout"], k_iters, tile, 1 if (transposed or residual_up2) else splits, transposed)
-    if tile in (3128, 3256):   # halo-stationary tiles split K over the 32-channel chunks only
-        splits = min(splits, pk["cin"] // 32)
+    if tile in (3128, 3256):   # halo-stationary tiles: stride-1 same-padded convolutions only, K split over the 32-channel chunks
+        if transposed or any(s != 1 for s in stride) or any(k % 2 == 0 or q != k // 2 for k, q in zip(kernel, pad)):
+            tile = 128256 if pk["cout"] > 128 else 128
+        else:
+            splits = min(splits, pk["cin"] // 32)
     ws = torch.empty((m * pk["cout"] * splits * 4,), dtype=torch.uint8, device=x.device) if splits > 1 else None
     i3 = lambda v: (ctypes.c_int * 3)(*v)
     st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
