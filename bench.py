@@ -266,6 +266,7 @@ def main():
     if args.graph:  # stage breakdown from a few eager steps outside the timed region (events cannot sit inside a graph)
         n_k1 = len(k1_events)
         for _ in range(5):
+            record["step"] = 0   # sample the per-launch conv events on each of these
             step_eager()
         torch.cuda.synchronize()
         del k1_events[n_k1:]

@@ -507,6 +507,9 @@ struct HaloGeom {
     int npd, nph, npw;     // patches per axis
     int HH, HW, NH;        // halo extents along H and W, halo rows in total
     int T;                 // taps
+    int KDL;               // 1: every tap reads the one halo image; kd: the depth taps are looped OUTSIDE the halo (the image has
+                           // no depth margin and is re-staged, shifted in depth, once per depth tap) -- a third of the LDS rows
+    int Tin;               // taps per staged image = T / KDL
 };
 
 // 16 bytes per lane, global -> LDS without registers: lane l lands at lds_dst + 16 l (lds_dst wave-uniform); lanes whose
@@ -560,8 +563,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_halo(const Conv3dParams p
         ce = (int)((int64_t)nch_all * (blockIdx.z + 1) / p.splits);
     }
     const int nch = ce - cb;
-    const int T = g.T;
+    const int T = g.T, Tin = g.Tin;
     const int S = nch * T;
+    const int nphase = nch * g.KDL;   // staged activation images: (chunk, looped depth tap)
 
     f32x4v acc[4][NT16];
 #pragma unroll
@@ -573,17 +577,25 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_halo(const Conv3dParams p
         // ---------------- producers ----------------
         const int stid = tid & 255;
         const int pw4 = wave - 4;
-        const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, WS_OOB, 0x00020000);
+        // looped depth taps: the depth shift (kd - pd) rides in the scalar offset, the base pointer is moved back by pd slices
+        const int64_t slice = (int64_t)p.H * p.W * p.Cin;
+        const bool dloop = g.KDL > 1;
+        const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in - (dloop ? p.pd * slice : 0)), 0, WS_OOB, 0x00020000);
         const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc((void*)wsplit, 0, WS_OOB, 0x00020000);
-        unsigned avoff[NPIECE], adst[NPIECE];
+        unsigned avoff[NPIECE], adst[NPIECE], amask[NPIECE];   // amask bit k SET: looped depth tap k reads outside the grid
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) {
             const int idx = stid + 256 * i;
             const int row = idx >> 3, q = idx & 7;
             const int hw = row % g.HW, hh = (row / g.HW) % g.HH, hd = row / (g.HW * g.HH);
-            const int vd = d0 - p.pd + hd, vh = h0 - p.ph + hh, vw = w0 - p.pw + hw;
+            const int vd = d0 + hd - (dloop ? 0 : p.pd), vh = h0 - p.ph + hh, vw = w0 - p.pw + hw;
             const bool ok = row < g.NH && (unsigned)vd < (unsigned)p.D && (unsigned)vh < (unsigned)p.H && (unsigned)vw < (unsigned)p.W;
             avoff[i] = ok ? (unsigned)((((int64_t)vd * p.H + vh) * p.W + vw) * p.Cin * 4 + q * 16) : WS_OOB;
+            unsigned msk = 0;
+            if (dloop)
+                for (int k = 0; k < g.KDL; ++k)
+                    if ((unsigned)(vd + k - p.pd) >= (unsigned)p.D) msk |= 1u << k;
+            amask[i] = msk;
             // rows past the halo are never read: their pieces are not stored (adst = ~0u)
             adst[i] = row < g.NH ? (unsigned)((row * CBK + (((q >> 1) ^ ws_swz(row)) * 8) + (q & 1) * 4) * 2) : ~0u;
         }
@@ -610,10 +622,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_halo(const Conv3dParams p
             if (++dt == T) { dt = 0; ++dc; }
         };
         u32x4 ra[NPIECE];
-        auto load_a = [&](int c) {
-            const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((cb + c) * CBK * 4));
+        auto load_a = [&](int a) {   // staged image a = (chunk a / KDL, looped depth tap a % KDL)
+            const int c = a / g.KDL, kdl = a - c * g.KDL;
+            const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(((cb + c) * CBK + (dloop ? kdl * slice : 0)) * 4));
+            const unsigned sh = 31 - kdl;
 #pragma unroll
-            for (int i = 0; i < NPIECE; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(ares, avoff[i], soff, 0);
+            for (int i = 0; i < NPIECE; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(ares, ((amask[i] << sh) & WS_OOB) | avoff[i], soff, 0);
         };
         auto split_store_a = [&]() {
             char* base = reinterpret_cast<char*>(lds16);
@@ -636,19 +650,19 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_halo(const Conv3dParams p
         for (int u = 0; u < NSTAGE - 1; ++u)
             if (u < S) dma_b(u);
         split_store_a();
-        if (nch > 1) load_a(1);
+        if (nphase > 1) load_a(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weight tile 0 (and whatever else) has landed
         __syncthreads();                                     // P0
         int s = 0;
-        for (int ci = 0; ci < nch; ++ci) {
-            for (int t = 0; t < T; ++t, ++s) {
+        for (int ci = 0; ci < nphase; ++ci) {
+            for (int t = 0; t < Tin; ++t, ++s) {
                 if (s + NSTAGE - 1 < S) {
                     dma_b(s + NSTAGE - 1);
                     // tile s + 1 must have landed before the barrier; the NSTAGE - 2 younger tiles may stay in flight
                     // (completion is in order: right after a chunk boundary the next chunk's activation loads are younger
                     // than tile s + 1 and may stay in flight too)
                     if (NSTAGE == 3) {
-                        if (t == 0 && ci + 1 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB + NPIECE) : "memory");
+                        if (t == 0 && ci + 1 < nphase) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB + NPIECE) : "memory");
                         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
                     } else {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -658,10 +672,10 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_halo(const Conv3dParams p
                 }
                 __syncthreads();                             // P1
             }
-            if (ci + 1 < nch) {
-                split_store_a();                             // chunk ci + 1 (loaded during chunk ci); the consumers wait at P2
+            if (ci + 1 < nphase) {
+                split_store_a();                             // image ci + 1 (loaded during image ci); the consumers wait at P2
                 __syncthreads();                             // P2
-                if (ci + 2 < nch) load_a(ci + 2);
+                if (ci + 2 < nphase) load_a(ci + 2);
             }
         }
     } else {
@@ -678,9 +692,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_halo(const Conv3dParams p
         const int wkh = p.kh, wkw = p.kw;
         __syncthreads();                                     // P0
         int s = 0;
-        for (int ci = 0; ci < nch; ++ci) {
-            int kd = 0, kh = 0, kw = 0;
-            for (int t = 0; t < T; ++t, ++s) {
+        for (int ci = 0; ci < nphase; ++ci) {
+            int kd = 0, kh = 0, kw = 0;   // tap inside the staged image (kd stays 0 when the depth taps are looped outside)
+            for (int t = 0; t < Tin; ++t, ++s) {
                 const int tapoff = (kd * g.HH + kh) * g.HW + kw;
                 const uint16_t* bst = Bs + (s % NSTAGE) * BSTAGE + boff;
                 bf16x8 fa[3][4], fb[3][NT16];
@@ -712,7 +726,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_halo(const Conv3dParams p
                 }
                 __syncthreads();                             // P1
             }
-            if (ci + 1 < nch) __syncthreads();               // P2
+            if (ci + 1 < nphase) __syncthreads();            // P2
         }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -739,22 +753,26 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_halo(const Conv3dParams p
 // patch shape for the halo tile: the power-of-two TD x TH x TW = 128 with the least padded work (weighted by the halo it drags)
 static bool halo_geometry(const Conv3dParams& p, int halo_max, HaloGeom& g) {
     double best = 1e30;
-    for (int ltd = 0; ltd <= 7; ++ltd)
-        for (int lth = 0; lth + ltd <= 7; ++lth) {
-            const int ltw = 7 - ltd - lth;
-            const int TD = 1 << ltd, TH = 1 << lth, TW = 1 << ltw;
-            const int HD = TD + p.kd - 1, HH = TH + p.kh - 1, HW = TW + p.kw - 1;
-            const int NH = HD * HH * HW;
-            if (NH > halo_max) continue;
-            const int npd = (p.OD + TD - 1) / TD, nph = (p.OH + TH - 1) / TH, npw = (p.OW + TW - 1) / TW;
-            const double waste = (double)npd * TD * nph * TH * npw * TW / ((double)p.OD * p.OH * p.OW);
-            const double cost = waste * (1.0 + 0.03 * NH / 128.0);
-            if (cost < best) {
-                best = cost;
-                g.ltd = ltd; g.lth = lth; g.ltw = ltw; g.npd = npd; g.nph = nph; g.npw = npw; g.HH = HH; g.HW = HW; g.NH = NH;
+    for (int dloop = 0; dloop <= (p.kd > 1 ? 1 : 0); ++dloop)   // depth taps inside the halo image, or looped outside it
+        for (int ltd = 0; ltd <= 7; ++ltd)
+            for (int lth = 0; lth + ltd <= 7; ++lth) {
+                const int ltw = 7 - ltd - lth;
+                const int TD = 1 << ltd, TH = 1 << lth, TW = 1 << ltw;
+                const int HD = dloop ? TD : TD + p.kd - 1, HH = TH + p.kh - 1, HW = TW + p.kw - 1;
+                const int NH = HD * HH * HW;
+                if (NH > halo_max) continue;
+                const int npd = (p.OD + TD - 1) / TD, nph = (p.OH + TH - 1) / TH, npw = (p.OW + TW - 1) / TW;
+                const double waste = (double)npd * TD * nph * TH * npw * TW / ((double)p.OD * p.OH * p.OW);
+                const int kdl = dloop ? p.kd : 1;
+                const double cost = waste * (1.0 + 0.03 * NH * kdl / 128.0);   // staged rows per chunk, relative to the tile
+                if (cost < best) {
+                    best = cost;
+                    g.ltd = ltd; g.lth = lth; g.ltw = ltw; g.npd = npd; g.nph = nph; g.npw = npw; g.HH = HH; g.HW = HW; g.NH = NH;
+                    g.KDL = kdl;
+                }
             }
-        }
     g.T = p.kd * p.kh * p.kw;
+    g.Tin = g.T / (best < 1e29 ? g.KDL : 1);
     return best < 1e29;
 }
 

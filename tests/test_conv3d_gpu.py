@@ -244,6 +244,8 @@ HALO_CASES = [
     (128, 300, (2, 15, 20), (1, 3, 3), 1, True, 2, 3256),     # odd map size, Cout ragged, split-K
     (64, 25, (10, 10, 4), (3, 3, 3), 0, False, 1, 3128),      # scalar-column epilogue
     (32, 128, (4, 9, 5), (3, 1, 3), 1, False, 1, 3128),       # mixed kernel extents, a single chunk
+    (64, 256, (6, 8, 16), (3, 3, 3), 1, True, 1, 3256),       # 3x3x3 on the 256-channel tile: depth taps looped outside the halo
+    (96, 288, (5, 7, 9), (3, 3, 3), 0, False, 3, 3256),       # the same, ragged everywhere, split-K
 ]
 
 
