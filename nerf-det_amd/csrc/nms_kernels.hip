@@ -7,8 +7,8 @@
 //   2. k_nms_mask      n x ceil(n/64) suppression bit matrix over the sorted list: bit (i, j) set when
 //                      picking i removes j, i.e. NOT (iou_ij * [class_i == class_j] <= thresh).  NaN IoU
 //                      (0/0 on zero-volume pairs) fails the <= and removes, exactly as the reference.
-//   3. k_nms_sweep     one wavefront walks the sorted list; the removed-set lives in one 64-bit word per lane,
-//                      rows are prefetched 8 deep so the walk is not latency bound.
+//   3. k_nms_sweep     one wavefront walks the sorted list 64 candidates at a time; the removed-set lives in one 64-bit
+//                      word per lane, the walk inside a block is a scalar bit loop, only the winners' rows are fetched.
 #include "ndet_common.hpp"
 
 #define NMS_MAX 4096
@@ -90,39 +90,61 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes
     mask[(int64_t)i * words + cb] = bits;
 }
 
+// 64 candidates at a time.  Inside a block the greedy walk only needs the block's own 64 x 64 corner of the bit matrix
+// (one word per candidate, one candidate per lane): a scalar loop over the still-alive bits -- find-first-set, read the
+// winner's word with v_readlane, clear what it suppresses -- with no memory access in the chain.  Only the rows of the
+// block's winners are then fetched (a few per block, issued together) and ORed into the removed-set of the later words.
+__device__ __forceinline__ unsigned long long nms_readlane64(unsigned long long v, int l) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long* __restrict__ mask, const int* __restrict__ order,
                                                   int n, int64_t* __restrict__ keep, int64_t* __restrict__ n_keep) {
     const int lane = threadIdx.x;
     const int words = (n + 63) / 64;  // <= 64
     unsigned long long removed = 0ull;  // lane w holds bits [64w, 64w+64)
-    constexpr int PF = 8;
-    unsigned long long row[PF];
-    int ord[PF];  // original index of candidate i, prefetched with its row (a load inside the serial chain costs ~0.5 us per pick)
-#pragma unroll
-    for (int k = 0; k < PF; ++k) {
-        row[k] = (k < n && lane < words && lane >= k / 64) ? mask[(int64_t)k * words + lane] : 0ull;
-        ord[k] = k < n ? order[k] : 0;
-    }
     int kept = 0;
-    for (int i0 = 0; i0 < n; i0 += PF) {
+    // this block's corner word and original index per candidate, fetched one block ahead
+    unsigned long long diag = lane < n ? mask[(int64_t)lane * words] : 0ull;
+    int ordv = lane < n ? order[lane] : 0;
+    for (int b = 0; b < words; ++b) {
+        const int base = b * 64;
+        const int nb = min(64, n - base);
+        const unsigned long long cur_diag = diag;
+        const int cur_ord = ordv;
+        {   // prefetch the next block's corner
+            const int c = base + 64 + lane;
+            diag = c < n ? mask[(int64_t)c * words + (b + 1)] : 0ull;
+            ordv = c < n ? order[c] : 0;
+        }
+        const unsigned long long valid = nb == 64 ? ~0ull : ((1ull << nb) - 1ull);
+        unsigned long long alive = ~nms_readlane64(removed, b) & valid;   // wave-uniform
+        unsigned long long winners = 0ull;
+        while (alive) {
+            const int i = __builtin_ctzll(alive);
+            const unsigned long long bit = 1ull << i;
+            winners |= bit;
+            alive &= ~bit;
+            alive &= ~nms_readlane64(cur_diag, i);
+        }
+        // keep[] in walk order: lane i's slot is the number of winners before it
+        if ((winners >> lane) & 1ull) keep[kept + __builtin_popcountll(winners & ((1ull << lane) - 1ull))] = (int64_t)cur_ord;
+        kept += __builtin_popcountll(winners);
+        // rows of the winners -> removed-set of the later blocks (words left of the diagonal were never written)
+        const bool later = lane > b && lane < words;
+        unsigned long long w = winners;
+        while (w) {
+            unsigned long long r[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int i = i0 + k;
-            if (i < n) {
-                // word i/64 of the removed-set lives in lane i/64: a scalar v_readlane, not a cross-lane shuffle,
-                // keeps the serial dependence (removed -> gone -> removed) short
-                const unsigned half = (i & 32) ? (unsigned)(removed >> 32) : (unsigned)removed;
-                const unsigned wsel = (unsigned)__builtin_amdgcn_readlane((int)half, i >> 6);
-                const bool gone = (wsel >> (i & 31)) & 1u;
-                if (!gone) {
-                    if (lane == 0) keep[kept] = (int64_t)ord[k];
-                    ++kept;
-                    removed |= row[k];
+            for (int k = 0; k < 4; ++k)
+                if (w) {
+                    const int i = __builtin_ctzll(w);
+                    w &= w - 1ull;
+                    if (later) r[k] = mask[(int64_t)(base + i) * words + lane];
                 }
-            }
-            const int nx = i + PF;  // refill this slot; words left of the diagonal were never written -> skip them
-            row[k] = (nx < n && lane < words && lane >= nx / 64) ? mask[(int64_t)nx * words + lane] : 0ull;
-            ord[k] = nx < n ? order[nx] : 0;
+            removed |= (r[0] | r[1]) | (r[2] | r[3]);
         }
     }
     if (lane == 0) *n_keep = kept;
