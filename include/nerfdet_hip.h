@@ -202,6 +202,25 @@ int ndet_conv_ndhwc_split(const float* in, const uint16_t* w_planes, float* out,
 int ndet_bn_relu_maxpool_nhwc(const float* x, const float* scale, const float* shift, int N, int H, int W, int C,
                               float* out, void* stream);
 
+/* ---- input contract: what the data pipeline hands to nerfdet.forward_*, from decoded,
+ * resized and padded uint8 BGR frames (n_frames,H,W,3) resident on the device.  mean_rgb / std_rgb are HOST arrays of 3
+ * doubles (the config's img_norm_cfg); the image arithmetic is float32 with stdinv = float(1 / std), as mmcv does it.
+ *
+ * ndet_normalize_views: for each selected frame ids[v]: img (n_sel,3,H,W) = mmcv.imnormalize(to_rgb=True), and
+ * denorm (n_sel,3,H,W) = imdenormalize(img, to_bgr=True).astype(uint8) / 255 -- the round trip of
+ * mmdet3d/datasets/pipelines/multi_view.py:107-110, channel-first as formating.py:44-52,80-85 stacks them. */
+int ndet_normalize_views(const uint8_t* frames_bgr, const int* ids, int n_sel, int H, int W, const double* mean_rgb,
+                         const double* std_rgb, float* img, float* denorm, void* stream);
+
+/* ndet_target_rays: the NeRF targets of multi_view.py:117-155 for frames target_ids[t]: rays on the pixel grid
+ * [margin, W-margin) x [margin, H-margin), row-major; raydirs (n_t,R,3) = get_dtu_raydir
+ * (data_augment_utils.py:410-424) with intrinsic_rows = rows 0,1 of intrinsic[:2]/ratio as a device (2,3) array and
+ * camrotc2w (n_frames,3,3); lightpos (n_t,R,3) = cam_lightpos[frame] repeated (formating.py:70-75); gt_images
+ * (n_t,R,3) = the de-normalised BGR frame / 255 at the ray's pixel (multi_view.py:147-150). */
+int ndet_target_rays(const uint8_t* frames_bgr, const int* target_ids, int n_targets, int H, int W, int margin,
+                     const float* intrinsic_rows, const float* camrotc2w, const float* cam_lightpos, const double* mean_rgb,
+                     const double* std_rgb, float* raydirs, float* lightpos, float* gt_images, void* stream);
+
 /* ---- backward passes (training).  The reference obtains these from autograd over its materialised tensors; each
  * entry point names the forward statement it differentiates.  Scatter targets must be zero-initialised by the caller;
  * accumulation uses float atomics (order not fixed). ---- */

@@ -15,13 +15,14 @@ Layout (only what the path needs):
   graphed.py        optional hipGraph replay of the static part of forward_test
   dist.py           one-process-per-GPU scene sharding, result gather, reductions
   eval.py           indoor mAP@0.25/0.5
+  pipeline.py       input contract: scene cameras, view sampling, normalised views + target rays on the GPU
   synth.py          deterministic synthetic ScanNet-shaped scenes for bench.py
 """
 from . import _lib  # noqa: F401
 from ._lib import LIB_PATH, NdetError  # noqa: F401
 
 _SUBMODULES = ("ops", "rays", "nms", "conv3d", "conv_tuning", "autograd", "volume", "radiance_field", "nerf_mlp", "backbone", "neck3d",
-               "head", "losses", "boxes", "detector", "registry", "config", "presets", "graphed", "dist", "eval", "synth")
+               "head", "losses", "boxes", "detector", "registry", "config", "presets", "graphed", "dist", "eval", "pipeline", "synth")
 __all__ = list(_SUBMODULES) + ["LIB_PATH", "NdetError"]
 
 

@@ -1,0 +1,106 @@
+// Input contract of the hot path: what MultiViewPipeline + DefaultFormatBundle3D hand to
+// nerfdet.forward_*, produced on the device from decoded, resized and padded uint8 frames.
+//
+//   k_normalize_views  mmcv.imnormalize(to_rgb=True) and the reference's own round trip
+//                      mmcv.imdenormalize(img, mean, std, to_bgr=True).astype(uint8) / 255 (multi_view.py:107-110), per
+//                      selected view, written channel-first as DefaultFormatBundle does (formating.py:44-52,80-85).
+//   k_target_rays      the NeRF targets of multi_view.py:117-155: margin-cropped pixel grid, get_dtu_raydir
+//                      (data_augment_utils.py:410-424, un-normalised), the camera centre repeated per ray
+//                      (formating.py:70-75) and the target colours gathered from the de-normalised frame.
+#include "ndet_common.hpp"
+
+__global__ __launch_bounds__(256) void k_normalize_views(const uint8_t* __restrict__ frames, const int* __restrict__ ids, int n_sel, int H, int W,
+                                                         float m0, float m1, float m2, float i0, float i1, float i2, float s0, float s1,
+                                                         float s2, float* __restrict__ img, float* __restrict__ denorm) {
+    const int64_t hw = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sel * hw) return;
+    const int v = (int)(i / hw);
+    const int64_t px = i - v * hw;
+    const uint8_t* src = frames + ((int64_t)ids[v] * hw + px) * 3;   // B, G, R
+    const float mean[3] = {m0, m1, m2}, inv[3] = {i0, i1, i2}, sd[3] = {s0, s1, s2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {   // c indexes RGB
+        const float x = ((float)src[2 - c] - mean[c]) * inv[c];
+        img[((int64_t)v * 3 + c) * hw + px] = x;
+        const float back = x * sd[c] + mean[c];                       // imdenormalize
+        const float q = (float)(unsigned char)(int)back;              // .astype(np.uint8): truncation
+        denorm[((int64_t)v * 3 + (2 - c)) * hw + px] = q / 255.0f;    // BGR planes
+    }
+}
+
+__global__ __launch_bounds__(256) void k_target_rays(const uint8_t* __restrict__ frames, const int* __restrict__ tids, int n_t, int H, int W, int margin,
+                                                     const float* __restrict__ kn /* (2,3): rows 0,1 of the scaled intrinsics */,
+                                                     const float* __restrict__ rot /* (n_frames,3,3) c2w rotations */,
+                                                     const float* __restrict__ lpos /* (n_frames,3) */, float m0, float m1, float m2, float i0,
+                                                     float i1, float i2, float s0, float s1, float s2, float* __restrict__ raydirs,
+                                                     float* __restrict__ lightpos, float* __restrict__ gt) {
+    const int rw = W - 2 * margin, rh = H - 2 * margin;
+    const int64_t per = (int64_t)rw * rh;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_t * per) return;
+    const int t = (int)(i / per);
+    const int r = (int)(i - t * per);
+    const int px = margin + r % rw, py = margin + r / rw;
+    const int f = tids[t];
+    const float x = ((float)px + 0.5f - kn[2]) / kn[0];
+    const float y = ((float)py + 0.5f - kn[5]) / kn[4];
+    const float* R = rot + (int64_t)f * 9;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float d = x * R[j * 3 + 0];
+        d = fmaf(y, R[j * 3 + 1], d);
+        d = d + R[j * 3 + 2];
+        raydirs[i * 3 + j] = d;
+        lightpos[i * 3 + j] = lpos[(int64_t)f * 3 + j];
+    }
+    const uint8_t* src = frames + (((int64_t)f * H + py) * W + px) * 3;
+    const float mean[3] = {m0, m1, m2}, inv[3] = {i0, i1, i2}, sd[3] = {s0, s1, s2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float xx = ((float)src[2 - c] - mean[c]) * inv[c];
+        const float back = xx * sd[c] + mean[c];
+        gt[i * 3 + (2 - c)] = (float)(unsigned char)(int)back / 255.0f;
+    }
+}
+
+extern "C" int ndet_normalize_views(const uint8_t* frames_bgr, const int* ids, int n_sel, int H, int W, const double* mean_rgb,
+                                    const double* std_rgb, float* img, float* denorm, void* stream) {
+    const char* fn = "ndet_normalize_views";
+    NDET_REQUIRE(frames_bgr && ids && mean_rgb && std_rgb && img && denorm, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(n_sel > 0 && H > 0 && W > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
+    float inv[3], mean[3], sd[3];
+    for (int c = 0; c < 3; ++c) {
+        NDET_REQUIRE(std_rgb[c] > 0.0, NDET_E_INVALID, "%s: std must be positive", fn);
+        inv[c] = (float)(1.0 / std_rgb[c]);   // mmcv: stdinv = 1 / np.float64(std), applied to the float32 image
+        mean[c] = (float)mean_rgb[c];
+        sd[c] = (float)std_rgb[c];
+    }
+    const int64_t total = (int64_t)n_sel * H * W;
+    hipLaunchKernelGGL(k_normalize_views, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, frames_bgr, ids, n_sel, H, W,
+                       mean[0], mean[1], mean[2], inv[0], inv[1], inv[2], sd[0], sd[1], sd[2], img, denorm);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
+
+extern "C" int ndet_target_rays(const uint8_t* frames_bgr, const int* target_ids, int n_targets, int H, int W, int margin,
+                                const float* intrinsic_rows /* device (2,3) */, const float* camrotc2w, const float* cam_lightpos,
+                                const double* mean_rgb, const double* std_rgb, float* raydirs, float* lightpos, float* gt_images, void* stream) {
+    const char* fn = "ndet_target_rays";
+    NDET_REQUIRE(frames_bgr && target_ids && intrinsic_rows && camrotc2w && cam_lightpos && mean_rgb && std_rgb && raydirs && lightpos && gt_images,
+                 NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(n_targets > 0 && H > 0 && W > 0 && margin >= 0 && 2 * margin < H && 2 * margin < W, NDET_E_INVALID, "%s: bad sizes / margin", fn);
+    float inv[3], mean[3], sd[3];
+    for (int c = 0; c < 3; ++c) {
+        NDET_REQUIRE(std_rgb[c] > 0.0, NDET_E_INVALID, "%s: std must be positive", fn);
+        inv[c] = (float)(1.0 / std_rgb[c]);
+        mean[c] = (float)mean_rgb[c];
+        sd[c] = (float)std_rgb[c];
+    }
+    const int64_t total = (int64_t)n_targets * (H - 2 * margin) * (W - 2 * margin);
+    hipLaunchKernelGGL(k_target_rays, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, frames_bgr, target_ids, n_targets, H, W,
+                       margin, intrinsic_rows, camrotc2w, cam_lightpos, mean[0], mean[1], mean[2], inv[0], inv[1], inv[2], sd[0], sd[1], sd[2], raydirs,
+                       lightpos, gt_images);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
