@@ -120,6 +120,22 @@ int ndet_head_decode(const float* raw, int n_cls, const uint8_t* valid, const fl
                      const float* voxel_size_host, const float* origin_host, float* best, int64_t* label, float* boxes,
                      void* stream);
 
+/* valid mask of an FPN level: F.interpolate(valid, size, mode='trilinear').round().bool() of
+ * mmdet3d/models/dense_heads/imvoxel_head_v2.py:442-449 for the integer down-scale `factor` (1 or even) of the level:
+ * valid (X,Y,Z) float view counts -> out (X/f,Y/f,Z/f) uint8. */
+int ndet_level_valid(const float* valid, int X, int Y, int Z, int factor, uint8_t* out, void* stream);
+
+/* `scores > score_thr` over the concatenated levels (imvoxel_head_v2.py:533-545) as one order-preserving compaction:
+ * best/label/boxes are HOST arrays of n_levels device pointers (per-level outputs of ndet_head_decode), n the level sizes;
+ * survivors go to out_* in level-then-voxel order, counts (device, n_levels + 1 ints) = per level, then the total. */
+int ndet_select_candidates(int n_levels, const float* const* best, const int64_t* const* label, const float* const* boxes,
+                           const int* n, float score_thr, float* out_best, int64_t* out_label, float* out_boxes, int* counts,
+                           void* stream);
+
+/* picked candidates -> detections in pick order: (centre, size) boxes, scores, labels (imvoxel_head_v2.py:546-555). */
+int ndet_gather_detections(const int64_t* keep, int n_keep, const float* boxes, const float* scores, const int64_t* labels,
+                           float* out_boxes, float* out_scores, int64_t* out_labels, void* stream);
+
 /* A9. Samples along rays. Replaces sample_along_camera_ray(), mmdet3d/models/model_utils/render_ray.py:145-189
  * (inv_uniform=False).  ray_o, ray_d (R,3); t_rand NULL (det=True) or (R,S) uniforms in [0,1) -- the stream the
  * reference draws with torch.rand_like, injectable for parity.  Outputs pts (R,S,3), z_vals (R,S). */

@@ -47,6 +47,9 @@ SIGNATURES = {
     "ndet_composite_bwd": ([_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P], c_int),
     "ndet_split_weights_bf16x3": ([_P, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_conv_ndhwc_split": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P], c_int),
+    "ndet_level_valid": ([_P, c_int, c_int, c_int, c_int, _P, _P], c_int),
+    "ndet_select_candidates": ([c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P], c_int),
+    "ndet_gather_detections": ([_P, c_int, _P, _P, _P, _P, _P, _P, _P], c_int),
     "ndet_normalize_views": ([_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P], c_int),
     "ndet_target_rays": ([_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
     "ndet_bn_relu_maxpool_nhwc": ([_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P], c_int),

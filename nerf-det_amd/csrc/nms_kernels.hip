@@ -228,3 +228,134 @@ extern "C" int ndet_head_decode(const float* raw, int n_cls, const uint8_t* vali
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Head post-processing between the decode and the NMS in two launches instead of ~60 library kernels.
+//
+// k_level_valid: `F.interpolate(valid, size, mode='trilinear').round().bool()` of imvoxel_head_v2.py:442-449 for the
+// integer down-scales the FPN levels have (1, 2, 4, ...): with align_corners=False an even factor f samples exactly half
+// way between input voxels f i + f/2 - 1 and f i + f/2 on every axis, so the value is the mean of that 2x2x2 block
+// (weights 0.125, exact in fp32 for view counts); round-half-even then bool = "mean > 0.5".
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_level_valid(const float* __restrict__ valid, int X, int Y, int Z, int f, uint8_t* __restrict__ out) {
+    const int nx = X / f, ny = Y / f, nz = Z / f;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nx * ny * nz) return;
+    const int iz = n % nz, iy = (n / nz) % ny, ix = n / (nz * ny);
+    if (f == 1) {
+        out[n] = rintf(valid[n]) != 0.0f;
+        return;
+    }
+    const int x0 = f * ix + f / 2 - 1, y0 = f * iy + f / 2 - 1, z0 = f * iz + f / 2 - 1;
+    float s = 0.0f;
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dz = 0; dz < 2; ++dz) s += 0.125f * valid[((int64_t)(x0 + dx) * Y + (y0 + dy)) * Z + (z0 + dz)];
+    out[n] = rintf(s) != 0.0f;
+}
+
+extern "C" int ndet_level_valid(const float* valid, int X, int Y, int Z, int factor, uint8_t* out, void* stream) {
+    const char* fn = "ndet_level_valid";
+    NDET_REQUIRE(valid && out, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(X > 0 && Y > 0 && Z > 0 && factor >= 1, NDET_E_INVALID, "%s: sizes must be positive", fn);
+    NDET_REQUIRE(factor == 1 || (factor % 2 == 0 && X % factor == 0 && Y % factor == 0 && Z % factor == 0), NDET_E_UNSUPPORTED,
+                 "%s: factor %d must be 1 or an even divisor of the grid", fn, factor);
+    const int n = (X / factor) * (Y / factor) * (Z / factor);
+    hipLaunchKernelGGL(k_level_valid, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, valid, X, Y, Z, factor, out);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
+
+// k_select_candidates: `scores > score_thr` over the concatenated levels (imvoxel_head_v2.py:533-545), order-preserving
+// compaction by one workgroup (ballot + wave prefix + LDS), so the candidate list -- and with it every tie-break of the
+// NMS -- is reproducible.  counts[l] = survivors of level l, counts[n_levels] = total.
+struct SelectLevels {
+    const float* best[4];
+    const int64_t* label[4];
+    const float* boxes[4];
+    int n[4];
+    int n_levels;
+};
+
+__global__ __launch_bounds__(1024) void k_select_candidates(const SelectLevels lv, float thr, float* __restrict__ o_best, int64_t* __restrict__ o_label,
+                                                            float* __restrict__ o_boxes, int* __restrict__ counts) {
+    __shared__ int wave_cnt[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int l = 0; l < lv.n_levels; ++l) {
+        const int level_base = base_s;
+        for (int i0 = 0; i0 < lv.n[l]; i0 += 1024) {
+            const int i = i0 + tid;
+            const bool keep = i < lv.n[l] && lv.best[l][i] > thr;
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) wave_cnt[wave] = __popcll(m);
+            __syncthreads();
+            int off = base_s;
+            for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+            if (keep) {
+                const int o = off + __popcll(m & ((1ull << lane) - 1ull));
+                o_best[o] = lv.best[l][i];
+                o_label[o] = lv.label[l][i];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o_boxes[(int64_t)o * 6 + k] = lv.boxes[l][(int64_t)i * 6 + k];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int t = 0;
+                for (int w = 0; w < 16; ++w) t += wave_cnt[w];
+                base_s += t;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) counts[l] = base_s - level_base;
+    }
+    if (tid == 0) counts[lv.n_levels] = base_s;
+}
+
+extern "C" int ndet_select_candidates(int n_levels, const float* const* best, const int64_t* const* label, const float* const* boxes,
+                                      const int* n, float score_thr, float* out_best, int64_t* out_label, float* out_boxes, int* counts,
+                                      void* stream) {
+    const char* fn = "ndet_select_candidates";
+    NDET_REQUIRE(best && label && boxes && n && out_best && out_label && out_boxes && counts, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(n_levels >= 1 && n_levels <= 4, NDET_E_UNSUPPORTED, "%s: 1..4 levels", fn);
+    SelectLevels lv;
+    lv.n_levels = n_levels;
+    for (int l = 0; l < n_levels; ++l) {
+        NDET_REQUIRE(best[l] && label[l] && boxes[l] && n[l] > 0, NDET_E_INVALID, "%s: level %d: null pointer / empty", fn, l);
+        lv.best[l] = best[l]; lv.label[l] = label[l]; lv.boxes[l] = boxes[l]; lv.n[l] = n[l];
+    }
+    hipLaunchKernelGGL(k_select_candidates, dim3(1), dim3(1024), 0, (hipStream_t)stream, lv, score_thr, out_best, out_label, out_boxes, counts);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
+
+// picked candidates -> (centre, size) boxes, scores, labels in pick order (imvoxel_head_v2.py:546-555)
+__global__ __launch_bounds__(256) void k_gather_detections(const int64_t* __restrict__ keep, int n_keep, const float* __restrict__ boxes,
+                                                           const float* __restrict__ scores, const int64_t* __restrict__ labels,
+                                                           float* __restrict__ o_boxes, float* __restrict__ o_scores, int64_t* __restrict__ o_labels) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_keep) return;
+    const int64_t k = keep[i];
+    const float* b = boxes + k * 6;
+    float* o = o_boxes + (int64_t)i * 6;
+    o[0] = (b[0] + b[3]) / 2.0f; o[1] = (b[1] + b[4]) / 2.0f; o[2] = (b[2] + b[5]) / 2.0f;
+    o[3] = b[3] - b[0]; o[4] = b[4] - b[1]; o[5] = b[5] - b[2];
+    o_scores[i] = scores[k];
+    o_labels[i] = labels[k];
+}
+
+extern "C" int ndet_gather_detections(const int64_t* keep, int n_keep, const float* boxes, const float* scores, const int64_t* labels,
+                                      float* out_boxes, float* out_scores, int64_t* out_labels, void* stream) {
+    const char* fn = "ndet_gather_detections";
+    NDET_REQUIRE(keep && boxes && scores && labels && out_boxes && out_scores && out_labels, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(n_keep > 0, NDET_E_INVALID, "%s: n_keep must be positive", fn);
+    hipLaunchKernelGGL(k_gather_detections, dim3((n_keep + 255) / 256), dim3(256), 0, (hipStream_t)stream, keep, n_keep, boxes, scores, labels,
+                       out_boxes, out_scores, out_labels);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}

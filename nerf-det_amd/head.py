@@ -153,10 +153,12 @@ class ScanNetImVoxelHeadV2(nn.Module):
                 and x[0].shape[0] == 1 and self.reg_conv.out_channels == 6)
 
     def simple_test_fused(self, x, valid, img_metas):
-        """forward + get_bboxes for one scene with the per-level elementwise chain in one kernel
-        (csrc/nms_kernels.hip::k_head_decode): fused head conv -> decode (best score, label, box per voxel) ->
-        top-``nms_pre`` per level -> threshold -> greedy NMS.  Same candidates in the same order as
-        :meth:`get_bboxes` (imvoxel_head_v2.py:216-285,528-545)."""
+        """forward + get_bboxes for one scene in a dozen launches: fused head conv -> level mask -> decode (best score, label,
+        box per voxel; csrc/nms_kernels.hip::k_head_decode) -> one order-preserving ``score > thr`` compaction over all
+        levels -> greedy NMS -> detections.  Same candidates as :meth:`get_bboxes` (imvoxel_head_v2.py:216-285,528-555):
+        a level's top-``nms_pre`` cut only matters when more than ``nms_pre`` of its voxels clear the score threshold, and is
+        then taken over the survivors.  More than four levels fall back to the generic library-op path below."""
+        import ctypes
         import numpy as np
         from ctypes import c_void_p
         from . import _lib
@@ -166,12 +168,19 @@ class ScanNetImVoxelHeadV2(nn.Module):
         pk = packed([self.centerness_conv, self.reg_conv, self.cls_conv])
         dev = x[0].device
         st = c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        gx0, gy0, gz0 = valid.shape[-3:]
+        v0 = valid.reshape(gx0, gy0, gz0).float().contiguous()
         bests, labels, boxes = [], [], []
         for i, (f, sc) in enumerate(zip(x, self.scales)):
             raw = conv3d_ndhwc(to_ndhwc(f[0].float()), pk)  # (X,Y,Z,25)
             gx, gy, gz = raw.shape[:3]
             n = gx * gy * gz
-            v = nn.functional.interpolate(valid, size=(gx, gy, gz), mode="trilinear").round().bool().reshape(-1).contiguous()
+            fac = gx0 // gx
+            if fac >= 1 and (fac == 1 or fac % 2 == 0) and (gx * fac, gy * fac, gz * fac) == (gx0, gy0, gz0):
+                v = torch.empty((n,), dtype=torch.uint8, device=dev)
+                check(lib.ndet_level_valid(c_void_p(v0.data_ptr()), gx0, gy0, gz0, fac, c_void_p(v.data_ptr()), st), "level_valid")
+            else:
+                v = nn.functional.interpolate(valid, size=(gx, gy, gz), mode="trilinear").round().bool().reshape(-1).contiguous()
             best = torch.empty((n,), dtype=torch.float32, device=dev)
             lab = torch.empty((n,), dtype=torch.int64, device=dev)
             box = torch.empty((n, 6), dtype=torch.float32, device=dev)
@@ -179,12 +188,55 @@ class ScanNetImVoxelHeadV2(nn.Module):
             check(lib.ndet_head_decode(c_void_p(raw.data_ptr()), self.n_classes, c_void_p(v.data_ptr()), c_void_p(sc.scale.data_ptr()),
                                        gx, gy, gz, float3(np.float32(vs)), float3(np.float32(np.asarray(meta["lidar2img"]["origin"]))),
                                        c_void_p(best.data_ptr()), c_void_p(lab.data_ptr()), c_void_p(box.data_ptr()), st), "head_decode")
-            if n > self.test_cfg.nms_pre > 0:
-                best, ids = best.topk(self.test_cfg.nms_pre)
-                lab, box = lab[ids], box[ids]
             bests.append(best)
             labels.append(lab)
             boxes.append(box)
+        nl = len(bests)
+        if nl <= 4:
+            sizes = [int(b.shape[0]) for b in bests]
+            tot = sum(sizes)
+            c_best = torch.empty((tot,), dtype=torch.float32, device=dev)
+            c_lab = torch.empty((tot,), dtype=torch.int64, device=dev)
+            c_box = torch.empty((tot, 6), dtype=torch.float32, device=dev)
+            counts = torch.empty((nl + 1,), dtype=torch.int32, device=dev)
+            pa = lambda ts: (ctypes.c_void_p * nl)(*[t.data_ptr() for t in ts])
+            check(lib.ndet_select_candidates(nl, pa(bests), pa(labels), pa(boxes), (ctypes.c_int * nl)(*sizes), float(self.test_cfg.score_thr),
+                                             c_void_p(c_best.data_ptr()), c_void_p(c_lab.data_ptr()), c_void_p(c_box.data_ptr()),
+                                             c_void_p(counts.data_ptr()), st), "select_candidates")
+            cnt = counts.cpu().tolist()   # host sync 1 of 2
+            pre = self.test_cfg.nms_pre
+            n = cnt[nl]
+            if pre > 0 and any(c > pre for c in cnt[:nl]):
+                # a level has more survivors than nms_pre: its top-nms_pre by score (all of them above the threshold, so the
+                # same set the reference's "top-k, then threshold" keeps); the other levels stay as compacted
+                pb, plab, pbox, off = [], [], [], 0
+                for c in cnt[:nl]:
+                    sb, sl, sx = c_best[off:off + c], c_lab[off:off + c], c_box[off:off + c]
+                    if c > pre:
+                        sb, ids = sb.topk(pre)
+                        sl, sx = sl[ids], sx[ids]
+                    pb.append(sb); plab.append(sl); pbox.append(sx)
+                    off += c
+                c_best, c_lab, c_box = torch.cat(pb), torch.cat(plab), torch.cat(pbox).contiguous()
+                n = int(c_best.shape[0])
+            if n == 0:
+                b = meta["box_type_3d"](c_box[:0], origin=(0.5, 0.5, 0.5), box_dim=6, with_yaw=False)
+                return [(b, c_best[:0], c_lab[:0])]
+            ids = aligned_3d_nms(c_box[:n], c_best[:n], c_lab[:n], self.test_cfg.iou_thr)   # host sync 2
+            k = int(ids.shape[0])
+            o_box = torch.empty((k, 6), dtype=torch.float32, device=dev)
+            o_sc = torch.empty((k,), dtype=torch.float32, device=dev)
+            o_lab = torch.empty((k,), dtype=torch.int64, device=dev)
+            if k:
+                check(lib.ndet_gather_detections(c_void_p(ids.data_ptr()), k, c_void_p(c_box.data_ptr()), c_void_p(c_best.data_ptr()),
+                                                 c_void_p(c_lab.data_ptr()), c_void_p(o_box.data_ptr()), c_void_p(o_sc.data_ptr()),
+                                                 c_void_p(o_lab.data_ptr()), st), "gather_detections")
+            return [(meta["box_type_3d"](o_box, origin=(0.5, 0.5, 0.5), box_dim=6, with_yaw=False), o_sc, o_lab)]
+        # generic path: per-level top-k, then threshold, NMS, box conversion with library ops
+        for i in range(nl):
+            if bests[i].shape[0] > self.test_cfg.nms_pre > 0:
+                bests[i], ids = bests[i].topk(self.test_cfg.nms_pre)
+                labels[i], boxes[i] = labels[i][ids], boxes[i][ids]
         best, lab, box = torch.cat(bests), torch.cat(labels), torch.cat(boxes)
         keep = best > self.test_cfg.score_thr
         best, lab, box = best[keep], lab[keep], box[keep]

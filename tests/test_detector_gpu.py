@@ -177,14 +177,34 @@ def test_graphed_forward_test_equals_eager(device):
         assert torch.equal(got[0]["boxes_3d"].tensor, eager[0]["boxes_3d"].tensor)
 
 
-def test_fused_head_decode_equals_standard_get_bboxes(device):
+def test_level_valid_equals_trilinear_round_bool(device):
+    """ndet_level_valid == F.interpolate(valid, size, 'trilinear').round().bool() for the FPN levels' down-scales."""
+    from ctypes import c_void_p
+    from nerfdet_amd import _lib
+    torch.manual_seed(5)
+    valid = ((torch.rand(1, 1, 24, 16, 8, device=device) < 0.3).float() * torch.randint(1, 4, (1, 1, 24, 16, 8), device=device).float())
+    lib = _lib.load()
+    st = c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    for f in (1, 2, 4):
+        size = (24 // f, 16 // f, 8 // f)
+        ref = torch.nn.functional.interpolate(valid, size=size, mode="trilinear").round().bool().reshape(-1)
+        out = torch.empty((size[0] * size[1] * size[2],), dtype=torch.uint8, device=device)
+        _lib.check(lib.ndet_level_valid(c_void_p(valid.data_ptr()), 24, 16, 8, f, c_void_p(out.data_ptr()), st), "level_valid")
+        assert torch.equal(out.bool(), ref), f
+        assert 0.02 < ref.float().mean() < 0.98
+    with pytest.raises(ValueError):
+        _lib.check(lib.ndet_level_valid(c_void_p(valid.data_ptr()), 24, 16, 8, 3, c_void_p(out.data_ptr()), st), "level_valid")
+
+
+@pytest.mark.parametrize("nms_pre", [300, 5000])   # 300: a level has more survivors than nms_pre -> generic path; 5000: fused path
+def test_fused_head_decode_equals_standard_get_bboxes(device, nms_pre):
     """simple_test_fused (one decode kernel per level) == forward + get_bboxes (the reference's op chain) on the GPU."""
     from nerfdet_amd.boxes import DepthInstance3DBoxes
     from nerfdet_amd.config import ConfigDict
     from nerfdet_amd.head import ScanNetImVoxelHeadV2
     torch.manual_seed(3)
     head = ScanNetImVoxelHeadV2(n_classes=18, n_channels=128, n_reg_outs=6, n_scales=3, limit=27, centerness_topk=18,
-                                test_cfg=ConfigDict(nms_pre=300, iou_thr=0.25, score_thr=0.01))
+                                test_cfg=ConfigDict(nms_pre=nms_pre, iou_thr=0.25, score_thr=0.01))
     head.voxel_size = (0.16, 0.16, 0.2)
     with torch.no_grad():
         head.cls_conv.weight.normal_(0, 0.05); head.cls_conv.bias.normal_(-2, 0.3)
