@@ -223,11 +223,13 @@ def main():
             if not record["on"]:
                 return det_gpu(return_loss=False, **batch)
             rb = det_gpu._ray_batch(batch)
+            # as nerfdet.extract_feat does: per-scene constants uploaded while the stream is still empty
+            geom = V.scene_geometry(batch["img_metas"][0], det_gpu.n_voxels, det_gpu.voxel_size, 4, device)
             e0 = ev()
             x, b, stride = det_gpu.extract_2d(batch["img"])
             e1 = ev()
             out = V.extract_volume(x, rb["denorm_images"][0], batch["img_metas"][0], det_gpu.n_voxels, det_gpu.voxel_size,
-                                   det_gpu.mapping, det_gpu.nerf_mlp, stride=stride, channels_last_out=True)
+                                   det_gpu.mapping, det_gpu.nerf_mlp, stride=stride, channels_last_out=True, geometry=geom)
             e2 = ev()
             x3 = det_gpu.neck_3d(out["volume"].unsqueeze(0))
             e3 = ev()

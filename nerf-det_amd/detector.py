@@ -10,7 +10,7 @@ from . import ops
 from .boxes import DepthInstance3DBoxes, bbox3d2result
 from .radiance_field import VanillaNeRFRadianceField
 from .registry import DETECTORS, build_backbone, build_head, build_neck
-from .volume import extract_volume
+from .volume import extract_volume, scene_geometry
 
 
 class BaseDetector(nn.Module):
@@ -111,6 +111,11 @@ class nerfdet(BaseDetector):
         assert depth is None, "depth is never forwarded to extract_feat by the reference (SURVEY.md 0.1)"
         assert ray_batch is not None and self.nerf_density and self.nerf_mode == "image", \
             "effective contract of the reference: use_ray=True, nerf_density=True, nerf_mode='image' (SURVEY.md 0.2)"
+        # per-scene constants go to the GPU first: the (pageable) uploads synchronise with the stream, which is still empty
+        # here -- after the backbone they would stall the host until its ~200 queued launches have drained
+        geoms = None
+        if not torch.is_grad_enabled():
+            geoms = [scene_geometry(m, self.n_voxels, self.voxel_size, 4, img.device) for m in img_metas]
         x, batch, stride = self.extract_2d(img)
         n_v = x.shape[0] // batch
         denorm = ray_batch["denorm_images"]
@@ -120,7 +125,8 @@ class nerfdet(BaseDetector):
             dn = denorm.reshape([-1] + list(denorm.shape)[2:])
             # inference: channels-last volume straight into the MFMA conv neck; training: NCDHW for the library convs
             out = extract_volume(feat, dn, img_meta, self.n_voxels, self.voxel_size, self.mapping, self.nerf_mlp,
-                                 stride=stride, channels_last_out=not torch.is_grad_enabled())
+                                 stride=stride, channels_last_out=not torch.is_grad_enabled(),
+                                 geometry=None if geoms is None else geoms[b])
             if mode == "train" or self.render_testing:
                 from .rays import render_rays
                 rgb_preds.append(render_rays(ray_batch, None, None, out["feature_2d"], dn, self.aabb, self.near_far_range,
