@@ -46,19 +46,16 @@ def compute_projection(img_meta: dict, stride: int, device=None) -> Tensor:
 
     50 3x4 matrices built on the host with the reference's fp32 arithmetic: the per-view ``intrinsic @ extrinsic[:3]`` products
     are evaluated as ONE ``k @ [e_0[:3] | e_1[:3] | ...]`` (each output element is the same 3-term dot product; bit-identical to
-    the per-view loop, checked in tests/test_model_cpu.py, at a fourteenth of its dispatch cost), then one asynchronous
-    H2D copy from pinned memory (a pageable copy would stall the host until the stream has drained)."""
+    the per-view loop, checked in tests/test_model_cpu.py, at a fourteenth of its dispatch cost), then one H2D copy.  The copy
+    is from pageable memory and therefore waits for the stream to drain: callers upload the scene constants BEFORE they queue
+    the backbone (detector.extract_feat); pinning the 2.4 KB per call costs milliseconds on ROCm (measured) and is not done."""
     k = torch.tensor(np.asarray(img_meta["lidar2img"]["intrinsic"], dtype=np.float32)[:3, :3])
     k[:2] /= img_meta["ori_shape"][0] / (img_meta["img_shape"][0] / stride)
     ext = torch.from_numpy(np.stack([np.asarray(e, dtype=np.float32) for e in img_meta["lidar2img"]["extrinsic"]]))
     n = ext.shape[0]
     cols = ext[:, :3].permute(1, 0, 2).reshape(3, 4 * n).contiguous()
     proj = (k @ cols).reshape(3, n, 4).permute(1, 0, 2).contiguous()
-    if device is None:
-        return proj
-    if torch.device(device).type == "cuda":
-        return proj.pin_memory().to(device, non_blocking=True)
-    return proj.to(device)
+    return proj.to(device) if device is not None else proj
 
 
 # --------------------------------------------------------------------------------------------
