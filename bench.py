@@ -223,11 +223,11 @@ def main():
             if not record["on"]:
                 return det_gpu(return_loss=False, **batch)
             rb = det_gpu._ray_batch(batch)
-            # as nerfdet.extract_feat does: per-scene constants uploaded while the stream is still empty
-            geom = V.scene_geometry(batch["img_metas"][0], det_gpu.n_voxels, det_gpu.voxel_size, 4, device)
             e0 = ev()
             x, b, stride = det_gpu.extract_2d(batch["img"])
             e1 = ev()
+            # as nerfdet.extract_feat does: per-scene constants computed on the host behind the backbone queue, async upload
+            geom = V.scene_geometry(batch["img_metas"][0], det_gpu.n_voxels, det_gpu.voxel_size, stride, device)
             out = V.extract_volume(x, rb["denorm_images"][0], batch["img_metas"][0], det_gpu.n_voxels, det_gpu.voxel_size,
                                    det_gpu.mapping, det_gpu.nerf_mlp, stride=stride, channels_last_out=True, geometry=geom)
             e2 = ev()

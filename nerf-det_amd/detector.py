@@ -111,12 +111,11 @@ class nerfdet(BaseDetector):
         assert depth is None, "depth is never forwarded to extract_feat by the reference (SURVEY.md 0.1)"
         assert ray_batch is not None and self.nerf_density and self.nerf_mode == "image", \
             "effective contract of the reference: use_ray=True, nerf_density=True, nerf_mode='image' (SURVEY.md 0.2)"
-        # per-scene constants go to the GPU first: the (pageable) uploads synchronise with the stream, which is still empty
-        # here -- after the backbone they would stall the host until its ~200 queued launches have drained
+        x, batch, stride = self.extract_2d(img)
+        # per-scene constants: host arithmetic while the GPU works through the backbone queue, asynchronous upload
         geoms = None
         if not torch.is_grad_enabled():
-            geoms = [scene_geometry(m, self.n_voxels, self.voxel_size, 4, img.device) for m in img_metas]
-        x, batch, stride = self.extract_2d(img)
+            geoms = [scene_geometry(m, self.n_voxels, self.voxel_size, stride, img.device) for m in img_metas]
         n_v = x.shape[0] // batch
         denorm = ray_batch["denorm_images"]
         volumes, valids, rgb_preds = [], [], []

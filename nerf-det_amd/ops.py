@@ -41,21 +41,35 @@ def _f32c(t: Tensor) -> Tensor:
 # --------------------------------------------------------------------------------------------
 # A1
 # --------------------------------------------------------------------------------------------
+_STAGING = {}   # (n_views, device) -> [ring of pinned (n_views,3,4) buffers, next slot]
+
+
+def _upload_async(host: Tensor, device) -> Tensor:
+    """H2D copy that does not stall the host: through a small ring of pinned staging buffers allocated once (a pageable
+    copy waits for the stream to drain -- ~200 queued backbone launches at this point of the step; pinning per call costs
+    more than the stall)."""
+    key = (tuple(host.shape), str(device))
+    ring = _STAGING.get(key)
+    if ring is None:
+        ring = _STAGING[key] = [[torch.empty(host.shape, dtype=host.dtype).pin_memory() for _ in range(8)], 0]
+    buf = ring[0][ring[1]]
+    ring[1] = (ring[1] + 1) % len(ring[0])
+    buf.copy_(host)
+    return buf.to(device, non_blocking=True)
+
+
 def compute_projection(img_meta: dict, stride: int, device=None) -> Tensor:
     """(n_views,3,4) pixel projections ``K' @ E[:3]`` (nerfdet.py:363-378, angles=None).
 
-    50 3x4 matrices built on the host with the reference's fp32 arithmetic: the per-view ``intrinsic @ extrinsic[:3]`` products
-    are evaluated as ONE ``k @ [e_0[:3] | e_1[:3] | ...]`` (each output element is the same 3-term dot product; bit-identical to
-    the per-view loop, checked in tests/test_model_cpu.py, at a fourteenth of its dispatch cost), then one H2D copy.  The copy
-    is from pageable memory and therefore waits for the stream to drain: callers upload the scene constants BEFORE they queue
-    the backbone (detector.extract_feat); pinning the 2.4 KB per call costs milliseconds on ROCm (measured) and is not done."""
+    50 3x4 matrices: built on the host in the reference's fp32 op order (one tiny product per view, as the reference does:
+    batching them changes the library kernel -- and on a many-core host wakes its thread pool), one asynchronous H2D copy."""
     k = torch.tensor(np.asarray(img_meta["lidar2img"]["intrinsic"], dtype=np.float32)[:3, :3])
     k[:2] /= img_meta["ori_shape"][0] / (img_meta["img_shape"][0] / stride)
     ext = torch.from_numpy(np.stack([np.asarray(e, dtype=np.float32) for e in img_meta["lidar2img"]["extrinsic"]]))
-    n = ext.shape[0]
-    cols = ext[:, :3].permute(1, 0, 2).reshape(3, 4 * n).contiguous()
-    proj = (k @ cols).reshape(3, n, 4).permute(1, 0, 2).contiguous()
-    return proj.to(device) if device is not None else proj
+    proj = torch.stack([k @ e[:3] for e in ext])
+    if device is None:
+        return proj
+    return _upload_async(proj, device) if torch.device(device).type == "cuda" else proj.to(device)
 
 
 # --------------------------------------------------------------------------------------------

@@ -84,17 +84,3 @@ def test_losses_and_targets_cpu_math():
     ce = CrossEntropyLoss(use_sigmoid=True)(torch.tensor([0.3, -0.2]), torch.tensor([0.7, 0.1]), avg_factor=2.0)
     assert torch.allclose(ce, torch.nn.functional.binary_cross_entropy_with_logits(torch.tensor([0.3, -0.2]), torch.tensor([0.7, 0.1]), reduction="sum") / 2)
 
-
-def test_compute_projection_is_bit_identical_to_the_per_view_products():
-    """ops.compute_projection batches the per-view ``intrinsic @ extrinsic[:3]`` (nerfdet.py:363-378) into one product: same bits."""
-    import numpy as np
-    import torch
-    from nerfdet_amd import ops
-    from oracle import nerfdet_oracle as O
-    rng = np.random.RandomState(3)
-    for n_views in (1, 7, 50, 101):
-        meta = O.ring_scene_meta(n_views, (240, 320))
-        for e in meta["lidar2img"]["extrinsic"]:
-            e[:3] += rng.randn(3, 4).astype(np.float32) * 0.01
-        for stride in (1, 4):
-            assert torch.equal(ops.compute_projection(meta, stride), O.compute_projection(meta, stride))
