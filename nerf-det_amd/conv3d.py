@@ -62,18 +62,22 @@ def choose_tiling(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 
     return tile, splits
 
 
-def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 0, transposed: bool = False):
+def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 0, transposed: bool = False, halo_ok: bool = False):
     """Tile (64 = 64x64, 128 = 128x128, 12864 = 128 rows x 64 channels, 128256 = wave-specialised 128 rows x 256 channels, 3128 / 3256 = halo-stationary 128-voxel patch x 128 / 256 channels)
     and split-K factor for the bf16x3 kernel."""
     if tile == 0 and splits == 0:
         hit = TUNED_SPLIT.get((m, cout, k_iters, int(transposed)))
         if hit is not None:
             return hit
-    if tile == 0:
-        big = ((m + 127) // 128) * ((cout + 127) // 128)
-        if big >= 120 and cout > 64:
+    if tile == 0:   # shapes outside the measured table: the pattern the sweeps showed
+        mt = (m + 127) // 128
+        big = mt * ((cout + 127) // 128)
+        wide = mt * ((cout + 255) // 256)                        # 128 x 256 tiles
+        if cout > 128 and wide * max(1, min(32, k_iters // 24)) >= 192:
+            tile = 3256 if (halo_ok and mt >= 64) else 128256    # halo-stationary when the layer has taps to share
+        elif big >= 120 and cout > 64:
             tile = 128
-        elif cout <= 64 and (m + 127) // 128 >= 256:
+        elif cout <= 64 and mt >= 256:
             tile = 12864
         else:
             tile = 64
@@ -105,9 +109,11 @@ def split_planes(pk: dict) -> torch.Tensor:
 
 
 def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, residual_up2, relu, splits, tile, m, k_iters, flops):
-    tile, splits = choose_tiling_split(m, pk["cout"], k_iters, tile, 1 if (transposed or residual_up2) else splits, transposed)
-    if tile in (3128, 3256):   # halo-stationary tiles: stride-1 same-padded convolutions only, K split over the 32-channel chunks
-        if transposed or any(s != 1 for s in stride) or any(k % 2 == 0 or q != k // 2 for k, q in zip(kernel, pad)):
+    halo_ok = (not transposed and all(s == 1 for s in stride) and all(k % 2 == 1 and q == k // 2 for k, q in zip(kernel, pad))
+               and kernel[0] * kernel[1] * kernel[2] > 1)
+    tile, splits = choose_tiling_split(m, pk["cout"], k_iters, tile, 1 if (transposed or residual_up2) else splits, transposed, halo_ok)
+    if tile in (3128, 3256):   # halo-stationary tiles: stride-1 same-padded multi-tap convolutions only, K split over the channel chunks
+        if not halo_ok:
             tile = 128256 if pk["cout"] > 128 else 128
         else:
             splits = min(splits, pk["cin"] // 32)
