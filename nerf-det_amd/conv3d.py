@@ -32,11 +32,15 @@ def set_arithmetic(mode: str) -> str:
     return prev
 
 
-launch_hook = None  # bench.py: callable(flops, thunk) wrapping every MFMA-conv launch (event timing); None = direct
+launch_hook = None  # bench.py: callable(flops, thunk, kernel_name) wrapping every MFMA-conv launch (event timing); None = direct
+
+KERNEL_NAMES = {("bf16x3", 64): "k_conv_split<64,64,2,2>", ("bf16x3", 128): "k_conv_split<128,128,2,2>", ("bf16x3", 12864): "k_conv_split<128,64,2,2>",
+                ("bf16x3", 128256): "k_conv_split_ws", ("bf16x3", 3128): "k_conv_split_halo<4>", ("bf16x3", 3256): "k_conv_split_halo<8>",
+                ("f32", 64): "k_conv3d_igemm<64,64,2,2>", ("f32", 128): "k_conv3d_igemm<128,128,4,2>"}
 
 
-def _launch(flops, thunk):
-    return thunk() if launch_hook is None else launch_hook(flops, thunk)
+def _launch(flops, thunk, arith="f32", tile=0):
+    return thunk() if launch_hook is None else launch_hook(flops, thunk, KERNEL_NAMES.get((arith, tile), f"{arith}:{tile}"))
 
 
 def choose_tiling(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 0, transposed: bool = False):
@@ -125,7 +129,7 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
     d, h, w = dims
     _launch(flops, lambda: check(lib.ndet_conv_ndhwc_split(_ptr(x), _ptr(planes), _ptr(out), d, h, w, pk["cin"], pk["cout"], i3(kernel), i3(stride),
                                                           i3(pad), int(transposed), _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual),
-                                                          int(residual_up2), relu, splits, tile, _ptr(ws), st), "conv_ndhwc_split"))
+                                                          int(residual_up2), relu, splits, tile, _ptr(ws), st), "conv_ndhwc_split"), "bf16x3", tile)
     return out
 
 
@@ -246,7 +250,7 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
         ws = torch.empty((int(lib.ndet_conv3d_workspace_bytes(d, h, w, cin, cout, k, s, splits)),), dtype=torch.uint8, device=x.device)
     st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     _launch(flops, lambda: check(lib.ndet_conv3d_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), d, h, w, cin, cout, k, s, int(tr), _ptr(pk["scale"]),
-                                                       _ptr(pk["shift"]), _ptr(residual), relu, splits, tile, _ptr(ws), st), "conv3d_ndhwc"))
+                                                       _ptr(pk["shift"]), _ptr(residual), relu, splits, tile, _ptr(ws), st), "conv3d_ndhwc"), "f32", tile)
     return out
 
 
@@ -279,7 +283,7 @@ def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = No
     _launch(2 * m * cout * cin * kh * kw,
             lambda: check(lib.ndet_conv_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), n, h, w, cin, cout, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw),
                                               _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), int(residual_up2), relu, splits, tile, _ptr(ws), st),
-                          "conv2d_nhwc"))
+                          "conv2d_nhwc"), "f32", tile)
     return out
 
 
