@@ -222,3 +222,66 @@ def test_fused_head_decode_equals_standard_get_bboxes(device, nms_pre):
     assert torch.equal(l0, l1)
     torch.testing.assert_close(s1, s0, rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(b1.tensor, b0.tensor, rtol=1e-5, atol=1e-5)
+
+
+def _small_detector(device, seed=0):
+    from nerfdet_amd.config import _wrap
+    from nerfdet_amd.presets import nerfdet_cfg
+    from nerfdet_amd.registry import build_detector
+    torch.manual_seed(seed)
+    cfg = _wrap(nerfdet_cfg(50, n_voxels=(16, 16, 8), voxel_size=(0.4, 0.4, 0.4)))
+    cfg["test_cfg"]["nms_pre"] = 200
+    det = build_detector(cfg["model"], train_cfg=cfg["train_cfg"], test_cfg=cfg["test_cfg"])
+    with torch.no_grad():
+        det.neck.fpn_convs[0].conv.weight.mul_(1 / 30.0)
+        det.nerf_mlp.mlp.sigma_layer.output_layer.bias.fill_(2.0)
+        det.bbox_head.cls_conv.weight.normal_(0, 0.3)
+        det.bbox_head.cls_conv.bias.fill_(-2.0)
+        det.bbox_head.centerness_conv.weight.normal_(0, 0.1)
+        det.bbox_head.reg_conv.weight.normal_(0, 0.05)
+    return det.to(device).eval()
+
+
+def _scene(device, seed, n_v=6, hw=(64, 96)):
+    g = torch.Generator().manual_seed(seed)
+    rays = dict(lightpos=torch.zeros(1, 1, 4, 3, device=device), raydirs=torch.ones(1, 1, 4, 3, device=device),
+                gt_images=torch.zeros(1, 1, 4, 3, device=device), gt_depths=[], nerf_sizes=[torch.tensor([[2, 2, 3]])])
+    return (torch.randn(1, n_v, 3, *hw, generator=g).to(device), torch.rand(1, n_v, 3, *hw, generator=g).to(device),
+            O.ring_scene_meta(n_v, hw), rays)
+
+
+def test_forward_test_agrees_between_the_two_convolution_arithmetics(device):
+    """Exact fp32-MFMA kernels vs the 3-term bf16 split on the bf16 matrix cores: same detections, boxes to 1e-4."""
+    from nerfdet_amd import conv3d
+    det = _small_detector(device)
+    img, dn, meta, rays = _scene(device, 4)
+    out = {}
+    for mode in ("f32", "bf16x3"):
+        prev = conv3d.set_arithmetic(mode)
+        try:
+            with torch.no_grad():
+                out[mode] = det(img, [dict(meta)], return_loss=False, denorm_images=dn, **rays)[0]
+        finally:
+            conv3d.set_arithmetic(prev)
+    a, b = out["f32"], out["bf16x3"]
+    assert len(a["scores_3d"]) > 5
+    assert torch.equal(a["labels_3d"], b["labels_3d"])
+    torch.testing.assert_close(a["scores_3d"], b["scores_3d"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(a["boxes_3d"].tensor, b["boxes_3d"].tensor, rtol=1e-4, atol=1e-4)
+
+
+def test_forward_test_with_no_detection_and_with_unseen_scene(device):
+    """Edge cases of the fused post-processing: nothing clears the score threshold; no voxel is seen by any camera."""
+    det = _small_detector(device)
+    img, dn, meta, rays = _scene(device, 5)
+    det.bbox_head.test_cfg["score_thr"] = 0.9999
+    with torch.no_grad():
+        res = det(img, [dict(meta)], return_loss=False, denorm_images=dn, **rays)[0]
+    assert len(res["scores_3d"]) == 0 and res["boxes_3d"].tensor.shape[0] == 0 and res["labels_3d"].dtype == torch.int64
+    det.bbox_head.test_cfg["score_thr"] = 0.01
+    far = O.ring_scene_meta(6, (64, 96))
+    for e in far["lidar2img"]["extrinsic"]:
+        e[2, 3] -= 1000.0          # every voxel ends up behind every camera
+    with torch.no_grad():
+        res = det(img, [dict(far)], return_loss=False, denorm_images=dn, **rays)[0]
+    assert len(res["scores_3d"]) == 0   # the head masks voxels no view sees
