@@ -1,3 +1,4 @@
+# Scratch (GPU box): SQ / LDS counters of the bf16x3 convolution kernel on the 849-GFLOP layer, four rocprofv3 --pmc passes.
 set -e
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmcconv

@@ -1,3 +1,5 @@
+"""Scratch (GPU box): time the 849-GFLOP 3x3x3 256->256 layer on one tile of the bf16x3 kernel through the C ABI.
+   python tools/time_conv_tile.py [tile]   # 64 128 12864 128256 3128 3256"""
 import os, sys, ctypes, torch
 from torch import nn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,8 +27,3 @@ for i in range(6):
     ts.append(e0.elapsed_time(e1))
 print("TILE", TILE, "ms", sorted(ts)[2], "TF", 2*240000*256*6912/sorted(ts)[2]/1e9, flush=True)
 
-t = ws.cpu().view(16, 8).tolist()
-for r in t[:8]:
-    print("consumer: work %5d | barrier wait %5d" % (r[1]-r[0], r[2]-r[1]))
-for r in t[8:]:
-    print("producer: vmcnt wait %5d | split+ds_write %5d | load issue %5d | barrier %5d | total %5d" % (r[1]-r[0], r[2]-r[1], r[3]-r[2], r[4]-r[3], r[4]-r[0]))
