@@ -35,7 +35,7 @@ def set_arithmetic(mode: str) -> str:
 launch_hook = None  # bench.py: callable(flops, thunk, kernel_name) wrapping every MFMA-conv launch (event timing); None = direct
 
 KERNEL_NAMES = {("bf16x3", 64): "k_conv_split<64,64,2,2>", ("bf16x3", 128): "k_conv_split<128,128,2,2>", ("bf16x3", 12864): "k_conv_split<128,64,2,2>",
-                ("bf16x3", 128256): "k_conv_split_ws", ("bf16x3", 3128): "k_conv_split_halo<4>", ("bf16x3", 3256): "k_conv_split_halo<8>",
+                ("bf16x3", 128256): "k_conv_split_ws", ("bf16x3", 3128): "k_conv_split_halo<4,2>", ("bf16x3", 3256): "k_conv_split_halo<8,2>", ("bf16x3", 3257): "k_conv_split_halo<4,4>",
                 ("f32", 64): "k_conv3d_igemm<64,64,2,2>", ("f32", 128): "k_conv3d_igemm<128,128,4,2>"}
 
 
@@ -88,7 +88,7 @@ def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: 
     if splits == 0:
         if transposed:
             return tile, 1
-        tm, tn = {12864: (128, 64), 128256: (128, 256), 3128: (128, 128), 3256: (128, 256)}.get(tile, (tile, tile))
+        tm, tn = {12864: (128, 64), 128256: (128, 256), 3128: (128, 128), 3256: (128, 256), 3257: (128, 256)}.get(tile, (tile, tile))
         tiles = ((m + tm - 1) // tm) * ((cout + tn - 1) // tn)
         splits = 1
         while splits < 32 and k_iters // (splits + 1) >= 24 and tiles * (splits + 1) <= 768:
@@ -116,7 +116,7 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
     halo_ok = (not transposed and all(s == 1 for s in stride) and all(k % 2 == 1 and q == k // 2 for k, q in zip(kernel, pad))
                and kernel[0] * kernel[1] * kernel[2] > 1)
     tile, splits = choose_tiling_split(m, pk["cout"], k_iters, tile, 1 if (transposed or residual_up2) else splits, transposed, halo_ok)
-    if tile in (3128, 3256):   # halo-stationary tiles: stride-1 same-padded multi-tap convolutions only, K split over the channel chunks
+    if tile in (3128, 3256, 3257):   # halo-stationary tiles: stride-1 same-padded multi-tap convolutions only, K split over the channel chunks
         if not halo_ok:
             tile = 128256 if pk["cout"] > 128 else 128
         else:

@@ -530,11 +530,14 @@ struct HaloRowMap {
     }
 };
 
-template <int NT16>
-__global__ __launch_bounds__(512, 1) void k_conv_split_halo(const Conv3dParams p, const uint16_t* __restrict__ wsplit, const HaloGeom g) {
-    constexpr int BN = 32 * NT16;
-    constexpr int HALO_MAX = (NT16 == 4) ? 400 : 224;
-    constexpr int NSTAGE = (NT16 == 4) ? 3 : 2;
+// NT16: 16x16 tiles per consumer wave along N; WGN: consumer waves along N (2 along M).  <4,2>: 128 channels, <8,2>: 256 channels with
+// one consumer wave per SIMD, <4,4>: 256 channels with two consumer waves per SIMD (each covers the other's LDS latency).
+template <int NT16, int WGN>
+__global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const Conv3dParams p, const uint16_t* __restrict__ wsplit, const HaloGeom g) {
+    constexpr int BN = 16 * NT16 * WGN;
+    constexpr int NCONS = 2 * WGN, NTHR = 64 * (NCONS + 4);
+    constexpr int HALO_MAX = (BN == 128) ? 400 : 224;
+    constexpr int NSTAGE = (BN == 128) ? 3 : 2;
     constexpr int NPIECE = (HALO_MAX * 8 + 255) / 256;
     constexpr int APL = HALO_MAX * CBK, BPL = BN * CBK;   // one plane, elements
     constexpr int BSTAGE = 3 * BPL;
@@ -546,8 +549,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_halo(const Conv3dParams p
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool consumer = wave < 4;
-    const int wm = (wave & 3) >> 1, wn = wave & 1;
+    const bool consumer = wave < NCONS;
+    const int wm = (wave % NCONS) / WGN, wn = (wave % NCONS) % WGN;
     const int n0 = blockIdx.y * BN;
     const int TH = 1 << g.lth, TW = 1 << g.ltw;
     int pb = blockIdx.x;
@@ -575,8 +578,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_halo(const Conv3dParams p
 
     if (!consumer) {
         // ---------------- producers ----------------
-        const int stid = tid & 255;
-        const int pw4 = wave - 4;
+        const int stid = tid - 64 * NCONS;
+        const int pw4 = wave - NCONS;
         // looped depth taps: the depth shift (kd - pd) rides in the scalar offset, the base pointer is moved back by pd slices
         const int64_t slice = (int64_t)p.H * p.W * p.Cin;
         const bool dloop = g.KDL > 1;
@@ -745,7 +748,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_halo(const Conv3dParams p
                         Cs[(ta * 16 + (lane >> 4) * 4 + r) * CLDC + wn * (16 * NT16) + tb * 16 + (lane & 15)] = acc[ta][tb][r];
         }
         __syncthreads();
-        conv_store_rows_mapped<BN, 512>(p, Cs, CLDC, 64, n0, tid, 0, blockIdx.z, HaloRowMap{h * 64, g.ltw, g.lth, d0, h0, w0, p.OD, p.OH, p.OW});
+        conv_store_rows_mapped<BN, NTHR>(p, Cs, CLDC, 64, n0, tid, 0, blockIdx.z, HaloRowMap{h * 64, g.ltw, g.lth, d0, h0, w0, p.OD, p.OH, p.OW});
         __syncthreads();
     }
 }
@@ -776,9 +779,9 @@ static bool halo_geometry(const Conv3dParams& p, int halo_max, HaloGeom& g) {
     return best < 1e29;
 }
 
-template <int NT16>
+template <int NT16, int WGN>
 static int split_launch_halo(const Conv3dParams& p, hipStream_t st, const char* fn) {
-    constexpr int BN = 32 * NT16, HALO_MAX = (NT16 == 4) ? 400 : 224, NSTAGE = (NT16 == 4) ? 3 : 2;
+    constexpr int BN = 16 * NT16 * WGN, HALO_MAX = (BN == 128) ? 400 : 224, NSTAGE = (BN == 128) ? 3 : 2;
     NDET_REQUIRE(!p.transposed && p.sd == 1 && p.sh == 1 && p.sw == 1 && (p.kd & 1) && (p.kh & 1) && (p.kw & 1) && p.pd == p.kd / 2 &&
                      p.ph == p.kh / 2 && p.pw == p.kw / 2,
                  NDET_E_UNSUPPORTED, "%s: the halo tile needs a stride-1 same-padded convolution with odd kernel extents", fn);
@@ -793,11 +796,11 @@ static int split_launch_halo(const Conv3dParams& p, hipStream_t st, const char* 
     if (cs > lds) lds = cs;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_conv_split_halo<NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_conv_split_halo<NT16, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_conv_split_halo<NT16>, grid, dim3(512), lds, st, p, (const uint16_t*)p.w, g);
+    hipLaunchKernelGGL((k_conv_split_halo<NT16, WGN>), grid, dim3(64 * (2 * WGN + 4)), lds, st, p, (const uint16_t*)p.w, g);
     return NDET_OK;
 }
 
@@ -829,8 +832,9 @@ int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn)
         case 128: rc = split_launch_tile<128, 128, 2, 2>(p, st, fn); break;
         case 12864: rc = split_launch_tile<128, 64, 2, 2>(p, st, fn); break;
         case 128256: rc = split_launch_ws(p, st, fn); break;
-        case 3128: rc = split_launch_halo<4>(p, st, fn); break;
-        case 3256: rc = split_launch_halo<8>(p, st, fn); break;
+        case 3128: rc = split_launch_halo<4, 2>(p, st, fn); break;
+        case 3256: rc = split_launch_halo<8, 2>(p, st, fn); break;
+        case 3257: rc = split_launch_halo<4, 4>(p, st, fn); break;
         default: ndet_set_error("%s: unknown tile %d", fn, tile); return NDET_E_INVALID;
     }
     if (rc != NDET_OK) return rc;
@@ -876,7 +880,7 @@ extern "C" int ndet_conv_ndhwc_split(const float* in, const uint16_t* w_planes, 
     NDET_REQUIRE(in && w_planes && out && kernel && stride && pad, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
     NDET_REQUIRE((scale == nullptr) == (shift == nullptr), NDET_E_INVALID, "%s: scale and shift go together", fn);
-    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128 || tile == 12864 || tile == 128256 || tile == 3128 || tile == 3256), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
+    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128 || tile == 12864 || tile == 128256 || tile == 3128 || tile == 3256 || tile == 3257), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
     NDET_REQUIRE(Cin % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
     NDET_REQUIRE((((uintptr_t)in | (uintptr_t)w_planes) & 15) == 0, NDET_E_UNSUPPORTED, "%s: in / weights must be 16-byte aligned", fn);
     Conv3dParams p;

@@ -246,6 +246,8 @@ HALO_CASES = [
     (32, 128, (4, 9, 5), (3, 1, 3), 1, False, 1, 3128),       # mixed kernel extents, a single chunk
     (64, 256, (6, 8, 16), (3, 3, 3), 1, True, 1, 3256),       # 3x3x3 on the 256-channel tile: depth taps looped outside the halo
     (96, 288, (5, 7, 9), (3, 3, 3), 0, False, 3, 3256),       # the same, ragged everywhere, split-K
+    (64, 256, (3, 12, 16), (1, 3, 3), 1, True, 1, 3257),      # 256 channels on eight consumer waves (two per SIMD)
+    (96, 300, (5, 7, 9), (3, 3, 3), 2, True, 3, 3257),        # the same: 3x3x3, ragged, split-K, ReLU before the residual
 ]
 
 
