@@ -253,10 +253,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 // chunk swizzle of the unpadded 64-byte LDS rows: physical 16-byte chunk = chunk ^ ws_swz(row).  The 16 x 16 x 32 fragment
-// read (lane l: row l & 15, chunk l >> 4) is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... -- rows
-// {0-3,12-15} at chunk c together with rows 4-11 at chunk c ^ 1; the table [0,2,3,1] over (row >> 2) & 3 puts those 16
-// accesses on 16 distinct slots of the 256-byte bank row.
-__device__ __forceinline__ int ws_swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // [0,2,3,1]
+// read (lane l: row base + (l & 15), chunk l >> 4) is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... --
+// rows {0-3,12-15} at chunk c together with rows 4-11 at chunk c ^ 1.  XORing bit 1 of the chunk with bit 2 of the row puts
+// those 16 accesses on 16 distinct slots of the 256-byte bank row for ANY base row (exhaustive search over the 4-entry
+// tables on (row >> 2) & 3; the halo tiles read at arbitrary row offsets -- with a table that is only conflict-free for
+// 16-row-aligned bases half of their LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT 323 M -> 162 M on the 849-GFLOP layer).
+__device__ __forceinline__ int ws_swz(int row) { return (row >> 1) & 2; }
 #define WS_BM 128
 #define WS_BN 256
 #define WS_DEPTH 2

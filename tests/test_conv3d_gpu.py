@@ -248,6 +248,7 @@ HALO_CASES = [
     (96, 288, (5, 7, 9), (3, 3, 3), 0, False, 3, 3256),       # the same, ragged everywhere, split-K
     (64, 256, (3, 12, 16), (1, 3, 3), 1, True, 1, 3257),      # 256 channels on eight consumer waves (two per SIMD)
     (96, 300, (5, 7, 9), (3, 3, 3), 2, True, 3, 3257),        # the same: 3x3x3, ragged, split-K, ReLU before the residual
+    (256, 256, (2, 24, 32), (1, 3, 3), 1, False, 1, 3257),    # 8 chunks x 9 taps
 ]
 
 
