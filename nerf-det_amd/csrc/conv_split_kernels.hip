@@ -259,6 +259,13 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // tables on (row >> 2) & 3; the halo tiles read at arbitrary row offsets -- with a table that is only conflict-free for
 // 16-row-aligned bases half of their LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT 323 M -> 162 M on the 849-GFLOP layer).
 __device__ __forceinline__ int ws_swz(int row) { return (row >> 1) & 2; }
+// 16 bytes per lane, global -> LDS without registers: lane l lands at lds_dst + 16 l (lds_dst wave-uniform); lanes whose
+// offset is out of range write zeros.  (A plain function: the address-space cast does not survive the host pass of a
+// kernel template.)
+__device__ __forceinline__ void spl_dma16(__amdgpu_buffer_rsrc_t rsrc, uint16_t* lds_dst, unsigned voffset, unsigned soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
+}
+
 #define WS_BM 128
 #define WS_BN 256
 #define WS_DEPTH 2
@@ -332,24 +339,22 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
             }
             amask[i] = ~msk;
         }
+        // weight tile by LDS-DMA (no registers, no ds_write): lane (row = brow_ (+ 64 i), physical chunk = bkg) fetches the
+        // logical chunk physical ^ swizzle(row) of its row; the LDS image is lane-linear, 1 KB per wave instruction
         unsigned bvoff[BR];
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            const int co = n0 + brow_ + 64 * i;
-            bvoff[i] = co < p.Cout ? (unsigned)((co * CBK + bkg * 8) * 2) : WS_OOB;
+            const int row = brow_ + 64 * i, co = n0 + row;
+            bvoff[i] = co < p.Cout ? (unsigned)((co * CBK + ((bkg ^ ws_swz(row)) * 8)) * 2) : WS_OOB;
         }
+        const int pw4 = wave - 4;
         const unsigned wtile_b = (unsigned)p.Cout * CBK * 2;   // bytes of one weight plane of one K step
         // LDS destinations (bytes within a stage): the chunk swizzle depends on the row only through (row >> 2) & 3
-        unsigned adst[AR], bdst[BR];
+        unsigned adst[AR];
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int row = arow_ + 32 * i;
             adst[i] = (unsigned)((row * CBK + (((akq >> 1) ^ ws_swz(row)) * 8) + (akq & 1) * 4) * 2);
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const int row = brow_ + 64 * i;
-            bdst[i] = (unsigned)((3 * APL + row * CBK + ((bkg ^ ws_swz(row)) * 8)) * 2);
         }
 
         int nkd, nkh, nkw, ncs;   // the next tile to load: chunk outermost, taps innermost
@@ -358,27 +363,43 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
             ncs = it_begin / taps;
             nkd = t0 / (wkh * wkw); nkh = (t0 / wkw) % wkh; nkw = t0 % wkw;
         }
-        u32x4 ra[WS_DEPTH][AR], rb[WS_DEPTH][BR][3];
-        unsigned asoff = 0, bsoff = 0, tapsh = 31;
+        u32x4 ra[WS_DEPTH][AR];
+        unsigned asoff = 0, tapsh = 31;
+        int bkd = nkd, bkh = nkh, bkw = nkw, bcs = ncs;   // the weight tiles walk the same sequence on their own clock
+        unsigned soff = 0;
+        auto dma_b = [&](int u, bool live) {   // weight tile u -> stage u & 1 (past the end: the last tile again, into a stage nobody reads)
+            if (live) {
+                const int tap = p.transposed ? ztap : (bkd * wkh + bkh) * wkw + bkw;
+                soff = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)tap * cin_steps + bcs) * 3) * wtile_b);
+            }
+            uint16_t* stage = lds16 + (u & 1) * STAGE + 3 * APL;
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    spl_dma16(bres, stage + pl * BPL + (64 * i + pw4 * 16) * CBK, bvoff[i], __builtin_amdgcn_readfirstlane(soff + pl * wtile_b));
+            if (live) {
+                if (++bkw == wkw) {
+                    bkw = 0;
+                    if (++bkh == wkh) {
+                        bkh = 0;
+                        if (++bkd == wkd) { bkd = 0; ++bcs; }
+                    }
+                }
+            }
+        };
         auto load_tile = [&](int slot, bool live) {
             // scalar side of the addresses (the buffer instruction takes them from SGPRs).  A tile past the end of this
             // workgroup's K range (`live` false: the last WS_DEPTH steps) re-reads the previous tile -- legal addresses, the
             // copy is staged but never multiplied -- so no per-load select is needed
             if (live) {
                 const int tapw = (nkd * wkh + nkh) * wkw + nkw;                    // tap inside the walk (mask bit)
-                const int tap = p.transposed ? ztap : tapw;                        // tap inside the weights
                 asoff = __builtin_amdgcn_readfirstlane((unsigned)(((((int64_t)nkd * p.H + nkh) * p.W + nkw) * p.Cin + ncs * CBK) * 4));
-                bsoff = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)tap * cin_steps + ncs) * 3) * wtile_b);
                 tapsh = 31 - tapw;
             }
 #pragma unroll
             for (int i = 0; i < AR; ++i)   // (amask << (31 - tap)) has bit 31 set when this tap reads padding: offset >= 2^31 -> zeros
                 ra[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(ares, ((amask[i] << tapsh) & WS_OOB) | avoff[i], asoff, 0);
-#pragma unroll
-            for (int i = 0; i < BR; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    rb[slot][i][pl] = __builtin_amdgcn_raw_buffer_load_b128(bres, bvoff[i], __builtin_amdgcn_readfirstlane(bsoff + pl * wtile_b), 0);
             if (++nkw == wkw) {
                 nkw = 0;
                 if (++nkh == wkh) {
@@ -398,23 +419,25 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
                 *reinterpret_cast<uint2*>(base + adst[i] + APL * 2) = s1;
                 *reinterpret_cast<uint2*>(base + adst[i] + APL * 4) = s2;
             }
-#pragma unroll
-            for (int i = 0; i < BR; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(base + bdst[i] + pl * (BPL * 2)) = rb[slot][i][pl];
         };
 
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int d = 0; d < WS_DEPTH; ++d) load_tile(d, d < n_it);
         store_tile(0, 0);
+        dma_b(0, n_it > 0);
         load_tile(0, WS_DEPTH < n_it);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR) : "memory");   // weight tile 0 has landed (the AR younger activation loads may fly)
         __syncthreads();
         for (int j0 = 0; j0 < n_round; j0 += WS_DEPTH) {
 #pragma unroll
             for (int d = 0; d < WS_DEPTH; ++d) {   // tile j0 + d is being multiplied; stage tile j0 + d + 1 (ring slot (d + 1) % DEPTH)
+                // (the DMA goes after the ds_writes of the split: the compiler drains vmcnt before any LDS store that follows an
+                // LDS-DMA in program order)
                 store_tile((d + 1) % WS_DEPTH, (j0 + d + 1) & 1);
+                dma_b(j0 + d + 1, j0 + d + 1 < n_it);                // its stage was released by the barrier that ended step j0 + d - 1
                 load_tile((d + 1) % WS_DEPTH, j0 + d + 1 + WS_DEPTH < n_it);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR) : "memory");   // the weight tile has landed; completion is in order
                 __syncthreads();
             }
         }
@@ -513,13 +536,6 @@ struct HaloGeom {
                            // no depth margin and is re-staged, shifted in depth, once per depth tap) -- a third of the LDS rows
     int Tin;               // taps per staged image = T / KDL
 };
-
-// 16 bytes per lane, global -> LDS without registers: lane l lands at lds_dst + 16 l (lds_dst wave-uniform); lanes whose
-// offset is out of range write zeros.  (A plain function: the address-space cast does not survive the host pass of a
-// kernel template.)
-__device__ __forceinline__ void spl_dma16(__amdgpu_buffer_rsrc_t rsrc, uint16_t* lds_dst, unsigned voffset, unsigned soffset) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
-}
 
 // tile row -> GEMM row of the output voxel it holds (-1 outside the grid)
 struct HaloRowMap {
