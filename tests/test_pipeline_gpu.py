@@ -48,3 +48,20 @@ def test_pipeline_feeds_the_detector(device, g):
     assert len(batch["img_metas"][0]["lidar2img"]["extrinsic"]) == 6
     with pytest.raises(RuntimeError):
         pipe(torch.from_numpy(g["frames"]), cams, (48, 64, 3))
+
+
+def test_pipeline_batch_runs_through_forward_test(device, g):
+    """README usage: the batch the pipeline assembles is what nerfdet.forward_test takes."""
+    from nerfdet_amd import pipeline as P
+    from nerfdet_amd.config import _wrap
+    from nerfdet_amd.presets import nerfdet_cfg
+    from nerfdet_amd.registry import build_detector
+    torch.manual_seed(0)
+    cfg = _wrap(nerfdet_cfg(50, n_voxels=(16, 16, 8), voxel_size=(0.4, 0.4, 0.4)))
+    det = build_detector(cfg["model"], train_cfg=cfg["train_cfg"], test_cfg=cfg["test_cfg"]).to(device).eval()
+    cams = P.scene_cameras(dict(extrinsics=list(g["poses"]), intrinsics=g["intrinsic"], annos=dict(axis_align_matrix=g["axis_align"])))
+    frames = torch.randint(0, 256, (14, 64, 96, 3), dtype=torch.uint8, device=device)
+    batch = P.MultiViewPipeline(4, margin=3, loading="sequence", nerf_target_views=1)(frames, cams, (128, 192, 3))
+    with torch.no_grad():
+        res = det(return_loss=False, **batch)
+    assert set(res[0]) == {"boxes_3d", "scores_3d", "labels_3d"}
