@@ -40,6 +40,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no 
 WORKLOADS = {
     "cfg2": dict(n_views=50, img_hw=(240, 320), channels=256, n_voxels=(40, 40, 16), voxel_size=(0.16, 0.16, 0.2), depth=50),
     "cfg1": dict(n_views=10, img_hw=(240, 320), channels=256, n_voxels=(40, 40, 16), voxel_size=(0.16, 0.16, 0.2), depth=50),
+    "cfg5": dict(n_views=101, img_hw=(240, 320), channels=256, n_voxels=(80, 80, 32), voxel_size=(0.08, 0.08, 0.1), depth=50),
     "tiny": dict(n_views=6, img_hw=(64, 96), channels=256, n_voxels=(16, 16, 8), voxel_size=(0.4, 0.4, 0.4), depth=50),
 }
 
@@ -307,7 +308,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "scenes/sec (50-view 240x320, 40x40x16 voxels)",
+            "metric": f"scenes/sec ({w['n_views']}-view {w['img_hw'][0]}x{w['img_hw'][1]}, {'x'.join(map(str, w['n_voxels']))} voxels)",
             "value": world * args.steps / dt,
             "unit": "scenes/s",
             "n_gpus": world,
