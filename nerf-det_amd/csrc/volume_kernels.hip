@@ -22,6 +22,11 @@ extern "C" int ndet_version(void) { return 100; }
 extern "C" const char* ndet_last_error(void) { return g_err; }
 
 #define VOX_PER_TILE 16  // one workgroup = 4 waves x 4 voxels = 16 consecutive voxels (one z column at Z=16)
+// K2 gathers one float per lane and view (a 140-byte row): a batch is cheap in registers and the kernel is latency bound, so it
+// keeps many more views in flight than K1's 1-KiB rows allow
+#ifndef K2_BATCH
+#define K2_BATCH 4
+#endif
 #ifndef GATHER_BATCH
 #define GATHER_BATCH 4  // independent 1-KiB row loads a wave keeps in flight per voxel (tools/tune_k1.py: 4 beats 8/12/16)
 #endif
@@ -351,11 +356,12 @@ extern "C" int ndet_backproject_aggregate(const float* features_nhwc, int n_view
 struct DensityRound {
     unsigned long long mf, mr;  // views seeing the voxel in the stride-4 map / in the full-resolution image
     int off_f, off_r;           // per-lane (= per-view) offsets into the mapped map / one RGB plane
+    unsigned boff_f, boff_r;    // the same as byte offsets from the tensor base, view included (buffer-load path)
 };
 
 __device__ __forceinline__ DensityRound density_project(int v, int n_views, const float* __restrict__ proj, const float* __restrict__ rgb_proj,
                                                         float px, float py, float pz, int w, int h, int W, int H, int mrow_pitch, int cm,
-                                                        int rsy) {
+                                                        int rsy, int64_t mview_pitch = 0, int64_t rsv = 0) {
     int xf = 0, yf = 0, xr = 0, yr = 0;
     bool okf = false, okr = false;
     if (v < n_views) {
@@ -365,6 +371,8 @@ __device__ __forceinline__ DensityRound density_project(int v, int n_views, cons
     DensityRound r;
     r.off_f = yf * mrow_pitch + xf * cm;
     r.off_r = yr * rsy + xr;
+    r.boff_f = (unsigned)((v * mview_pitch + r.off_f) * 4);
+    r.boff_r = (unsigned)((v * rsv + r.off_r) * 4);
     r.mf = __ballot(okf);
     r.mr = __ballot(okr);
     return r;
@@ -381,10 +389,10 @@ __device__ __forceinline__ float density_round_pass(const DensityRound& d, int r
     unsigned long long m = d.mf | d.mr;
     int b = 0;
     while (m) {
-        float t[GATHER_BATCH];
-        bool has[GATHER_BATCH], mine[GATHER_BATCH];
+        float t[K2_BATCH];
+        bool has[K2_BATCH], mine[K2_BATCH];
 #pragma unroll
-        for (int k = 0; k < GATHER_BATCH; ++k) {
+        for (int k = 0; k < K2_BATCH; ++k) {
             has[k] = (m != 0ull);
             if (has[k]) {
                 b = __builtin_ctzll(m);
@@ -399,7 +407,7 @@ __device__ __forceinline__ float density_round_pass(const DensityRound& d, int r
             t[k] = mine[k] ? *p : 0.0f;
         }
 #pragma unroll
-        for (int k = 0; k < GATHER_BATCH; ++k) {
+        for (int k = 0; k < K2_BATCH; ++k) {
             if (has[k]) {
                 const float val = mine[k] ? t[k] : fill;
                 if (PASS == 0) {
@@ -414,6 +422,50 @@ __device__ __forceinline__ float density_round_pass(const DensityRound& d, int r
     return acc;
 }
 
+// The same pass with buffer loads: a view's offset (computed by the lane that projected it) becomes the instruction's scalar
+// offset, the lane's channel its constant vector offset -- no per-view address arithmetic in the vector unit, which is what
+// bounds this kernel (a 140-byte gather per voxel-view: ~30 instructions of pointer math against 2 loads).  Lanes of the other
+// kind (and idle lanes) carry an out-of-range offset and read zeros.
+#define K2_OOB 0x80000000u
+template <int PASS>
+__device__ __forceinline__ float density_round_pass_buf(const DensityRound& d, __amdgpu_buffer_rsrc_t mres, __amdgpu_buffer_rsrc_t rres,
+                                                        unsigned fvoff, unsigned rvoff, bool is_rgb, float fill, float mean, float acc) {
+    unsigned long long m = d.mf | d.mr;
+    int b = 0;
+    while (m) {
+        float tf[K2_BATCH], tr[K2_BATCH];
+        bool has[K2_BATCH], vf[K2_BATCH], vr[K2_BATCH];
+#pragma unroll
+        for (int k = 0; k < K2_BATCH; ++k) {
+            has[k] = (m != 0ull);
+            if (has[k]) {
+                b = __builtin_ctzll(m);
+                m &= (m - 1ull);
+            }
+            vf[k] = has[k] && ((d.mf >> b) & 1ull);
+            vr[k] = has[k] && ((d.mr >> b) & 1ull);
+            const unsigned of = (unsigned)__builtin_amdgcn_readlane((int)d.boff_f, b);
+            const unsigned orr = (unsigned)__builtin_amdgcn_readlane((int)d.boff_r, b);
+            tf[k] = vf[k] ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mres, fvoff, of, 0)) : 0.0f;
+            tr[k] = vr[k] ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rres, rvoff, orr, 0)) : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < K2_BATCH; ++k) {
+            if (has[k]) {
+                const float val = is_rgb ? (vr[k] ? tr[k] : fill) : (vf[k] ? tf[k] : fill);
+                if (PASS == 0) {
+                    acc = acc + val;
+                } else {
+                    const float dd = val - mean;
+                    acc = acc + dd * dd;
+                }
+            }
+        }
+    }
+    return acc;
+}
+
+template <bool BUF>
 __global__ __launch_bounds__(256) void k_density_features(const float* __restrict__ mapped, int n_views, int cm, int h, int w,
                                                           int64_t mview_pitch, int mrow_pitch, const float* __restrict__ bias,
                                                           const float* __restrict__ rgb, int H, int W, int64_t rsv, int64_t rsc,
@@ -427,6 +479,12 @@ __global__ __launch_bounds__(256) void k_density_features(const float* __restric
     const int F = 2 * (3 + cm);
     const float fill = (lane >= 3 && lane < 3 + cm) ? bias[lane - 3] : 0.0f;
     const bool single_round = n_views <= 64;  // the common case: projections are computed once and reused by both passes
+    const bool is_rgb = lane < 3;
+    // buffer path: per-lane constant offsets (the lane's channel), out of range for lanes of the other kind
+    const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)mapped, 0, K2_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)rgb, 0, K2_OOB, 0x00020000);
+    const unsigned fvoff = (lane >= 3 && lane < 3 + cm) ? (unsigned)((lane - 3) * 4) : K2_OOB;
+    const unsigned rvoff = is_rgb ? (unsigned)(lane * rsc * 4) : K2_OOB;
 
     float px[VPW], py[VPW], pz[VPW];
     bool live[VPW];
@@ -440,7 +498,7 @@ __global__ __launch_bounds__(256) void k_density_features(const float* __restric
     // the wave's 4 voxels are projected back to back (lanes over views) before any gather is issued
     DensityRound first[VPW];
 #pragma unroll
-    for (int j = 0; j < VPW; ++j) first[j] = density_project(lane, n_views, proj, rgb_proj, px[j], py[j], pz[j], w, h, W, H, mrow_pitch, cm, rsy);
+    for (int j = 0; j < VPW; ++j) first[j] = density_project(lane, n_views, proj, rgb_proj, px[j], py[j], pz[j], w, h, W, H, mrow_pitch, cm, rsy, mview_pitch, rsv);
 
 #pragma unroll
     for (int j = 0; j < VPW; ++j) {
@@ -450,10 +508,11 @@ __global__ __launch_bounds__(256) void k_density_features(const float* __restric
         int cnt = 0, n_union = 0;
         for (int r0 = 0; r0 < n_views; r0 += 64) {
             const DensityRound d = (r0 == 0) ? first[j]
-                                             : density_project(r0 + lane, n_views, proj, rgb_proj, px[j], py[j], pz[j], w, h, W, H, mrow_pitch, cm, rsy);
+                                             : density_project(r0 + lane, n_views, proj, rgb_proj, px[j], py[j], pz[j], w, h, W, H, mrow_pitch, cm, rsy, mview_pitch, rsv);
             cnt += __popcll(d.mf);
             n_union += __popcll(d.mf | d.mr);
-            sum = density_round_pass<0>(d, r0, mapped, mview_pitch, rgb, rsv, rsc, lane, cm, fill, 0.0f, sum);
+            sum = BUF ? density_round_pass_buf<0>(d, mres, rres, fvoff, rvoff, is_rgb, fill, 0.0f, sum)
+                      : density_round_pass<0>(d, r0, mapped, mview_pitch, rgb, rsv, rsc, lane, cm, fill, 0.0f, sum);
         }
         const float rest = (float)(n_views - n_union);
         sum = sum + rest * fill;
@@ -462,8 +521,9 @@ __global__ __launch_bounds__(256) void k_density_features(const float* __restric
         float ss = 0.0f;
         for (int r0 = 0; r0 < n_views; r0 += 64) {
             const DensityRound d = (r0 == 0 || single_round) ? first[j]
-                                                             : density_project(r0 + lane, n_views, proj, rgb_proj, px[j], py[j], pz[j], w, h, W, H, mrow_pitch, cm, rsy);
-            ss = density_round_pass<1>(d, r0, mapped, mview_pitch, rgb, rsv, rsc, lane, cm, fill, mean, ss);
+                                                             : density_project(r0 + lane, n_views, proj, rgb_proj, px[j], py[j], pz[j], w, h, W, H, mrow_pitch, cm, rsy, mview_pitch, rsv);
+            ss = BUF ? density_round_pass_buf<1>(d, mres, rres, fvoff, rvoff, is_rgb, fill, mean, ss)
+                     : density_round_pass<1>(d, r0, mapped, mview_pitch, rgb, rsv, rsc, lane, cm, fill, mean, ss);
         }
         const float dd = fill - mean;
         ss = ss + rest * (dd * dd);
@@ -486,9 +546,17 @@ extern "C" int ndet_density_features(const float* mapped_nhwc, int n_views, int 
                  "%s: one view exceeds 2^31 floats", fn);
     NDET_REQUIRE(((uintptr_t)global_feat & 7) == 0, NDET_E_UNSUPPORTED, "%s: global_feat must be 8-byte aligned", fn);
     const int n_tiles = (N + VOX_PER_TILE - 1) / VOX_PER_TILE;
-    hipLaunchKernelGGL(k_density_features, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, mapped_nhwc, n_views, cm, h, w,
-                       mview_pitch, (int)mrow_pitch, bias, rgb, H, W, rsv, rsc, (int)rsy, points, N, projection, rgb_projection,
-                       global_feat, n_tiles);
+    // both tensors within 2 GB: gathers as buffer loads with the view offset in the scalar register
+    const bool buf = (int64_t)n_views * mview_pitch * 4 < ((int64_t)1 << 31) && (int64_t)n_views * rsv * 4 < ((int64_t)1 << 31) &&
+                     mview_pitch >= 0 && rsv >= 0 && rsc >= 0;
+    if (buf)
+        hipLaunchKernelGGL(k_density_features<true>, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, mapped_nhwc, n_views, cm, h, w,
+                           mview_pitch, (int)mrow_pitch, bias, rgb, H, W, rsv, rsc, (int)rsy, points, N, projection, rgb_projection,
+                           global_feat, n_tiles);
+    else
+        hipLaunchKernelGGL(k_density_features<false>, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, mapped_nhwc, n_views, cm, h, w,
+                           mview_pitch, (int)mrow_pitch, bias, rgb, H, W, rsv, rsc, (int)rsy, points, N, projection, rgb_projection,
+                           global_feat, n_tiles);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
