@@ -285,3 +285,38 @@ def test_forward_test_with_no_detection_and_with_unseen_scene(device):
     with torch.no_grad():
         res = det(img, [dict(far)], return_loss=False, denorm_images=dn, **rays)[0]
     assert len(res["scores_3d"]) == 0   # the head masks voxels no view sees
+
+
+def test_full_size_cfg2_voxel_features_agree_between_arithmetics(device):
+    """BASELINE's full size (50 views 240x320, 40x40x16 voxels, ResNet-50): the voxel features the hot path produces from the
+    bf16x3 backbone agree with those from the exact fp32-MFMA backbone within the north-star tolerance (1e-4, relative to the
+    feature scale), the view counts exactly, and the detections are the same set."""
+    import importlib.util
+    import os
+    from nerfdet_amd import conv3d
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import nerfdet_amd.volume as V
+    w = bench.WORKLOADS["cfg2"]
+    det = bench.build_model(w).to(device)
+    batch = bench.to_device(bench.synth_batch(w, 0), device)
+    out, res = {}, {}
+    for mode in ("f32", "bf16x3"):
+        prev = conv3d.set_arithmetic(mode)
+        try:
+            with torch.no_grad():
+                x, b, stride = det.extract_2d(batch["img"])
+                out[mode] = V.extract_volume(x, batch["denorm_images"][0], batch["img_metas"][0], det.n_voxels, det.voxel_size,
+                                             det.mapping, det.nerf_mlp, stride=stride, channels_last_out=True)
+                res[mode] = det(return_loss=False, **{k: (list(v) if isinstance(v, list) else v) for k, v in batch.items()})[0]
+        finally:
+            conv3d.set_arithmetic(prev)
+    a, c = out["f32"], out["bf16x3"]
+    assert torch.equal(a["valid"], c["valid"]) and float((a["valid"] > 0).float().mean()) > 0.2
+    scale = max(1.0, float(a["volume"].abs().max()))
+    assert float((a["volume"] - c["volume"]).abs().max()) <= 1e-4 * scale
+    assert float((a["global_feat"] - c["global_feat"]).abs().max()) <= 1e-4 * max(1.0, float(a["global_feat"].abs().max()))
+    assert len(res["f32"]["scores_3d"]) > 50
+    assert torch.equal(res["f32"]["labels_3d"], res["bf16x3"]["labels_3d"])
+    torch.testing.assert_close(res["f32"]["scores_3d"], res["bf16x3"]["scores_3d"], rtol=1e-3, atol=1e-5)
