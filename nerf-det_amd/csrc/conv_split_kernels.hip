@@ -12,11 +12,15 @@
 // Layout: weights arrive pre-split as three bf16 planes, tiled per K step: (taps, Cin/32, 3, Cout, 32) -- the B tile of one
 // K step is one contiguous run per plane, so every staging load instruction covers 1 KB of whole cache lines
 // (ndet_split_weights_bf16x3 below, once per model);
-// activations stay fp32 channels-last in HBM and are split while they are staged into LDS.  LDS holds three bf16 planes
-// per operand, K-contiguous rows of 32 k (64 B) padded to 80 B so that the ds_read_b128 fragment reads (lane -> row
-// l & 31, k-octet l >> 5) fall on 16 distinct 16-byte slots per 16 lanes.  One LDS stage (60 KB at 128 x 128) with the
-// next K step prefetched into registers: two workgroups fit on a CU and cover each other's barrier / split phases.
-// Wave tile 64 x 64 (2 x 2 MFMA tiles of 32 x 32): 12 fragment reads feed 24 MFMAs per 16-k sub-step.
+// activations stay fp32 channels-last in HBM and are split while they are staged into LDS (three bf16 planes per operand).
+//
+// Three kernel families, chosen per layer (nerfdet_amd/conv_tuning.py, measured):
+//   k_conv_split<BM,BN>     every wave stages and multiplies (32x32x16 MFMAs, LDS rows padded to 80 B, one stage, next K step
+//                           prefetched in registers, two workgroups per CU cover each other) -- small / narrow layers;
+//   k_conv_split_ws         128 x 256, wave-specialised: 4 MFMA-only consumer waves (16x16x32), 4 producer waves (activation
+//                           split in registers, weight tiles by LDS-DMA), swizzled unpadded LDS rows, one barrier per step;
+//   k_conv_split_halo<..>   stride-1 same-padded multi-tap layers: the activation patch + halo is split once per channel
+//                           chunk and every tap multiplies out of that LDS image.
 #include "conv_common.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
