@@ -145,7 +145,45 @@ class VanillaNeRFRadianceField(nn.Module):
         out = self.mlp.sigma_layer.output_layer
         return ops.sigma_head(h, rows, n_in, out.weight, out.bias)
 
+    def forward_rows_hip(self, x, condition, features):
+        """Inference form of :meth:`forward` for the ray branch (A10, nerf_mlp.py:146-161,229-234): the dense layers of the trunk,
+        the bottleneck and the view-conditioned colour layer run on the hand-written MFMA convolution kernel as 1x1
+        convolutions over the (R*S) sample rows; the 389->1 and 128->3 output layers are per-row dot products."""
+        from . import ops
+        from .conv3d import linear_rows, packed_linear
+        lead = x.shape[:-1]
+        n = int(torch.tensor(lead).prod())
+        b = self.mlp.base
+        n_in = 63 + features.shape[-1]
+        width = (n_in + 31) // 32 * 32
+        rows = ops.posenc_concat(x.reshape(n, 3).t().contiguous(), features.reshape(n, -1), pad_to=width)
+        h = rows
+        for i, lin in enumerate(b.hidden_layers):
+            h = linear_rows(h, packed_linear(lin, pad_in_to=width if i == 0 else 0), relu=1)
+        out = self.mlp.sigma_layer.output_layer
+        _, raw_sigma = ops.sigma_head(h, rows, n_in, out.weight, out.bias, want_raw=True)
+        wide = (h.shape[1] + n_in + 31) // 32 * 32
+        hc = torch.zeros((n, wide), dtype=torch.float32, device=h.device)
+        hc[:, :h.shape[1]] = h
+        hc[:, h.shape[1]:h.shape[1] + n_in] = rows[:, :n_in]
+        bott = linear_rows(hc, packed_linear(self.mlp.bottleneck_layer.output_layer, pad_in_to=wide), relu=0)
+        cond = self.view_encoder(condition)
+        if cond.shape[:-1] != lead:   # one view direction per ray, broadcast over its samples
+            cond = cond.view([cond.shape[0]] + [1] * (len(lead) - 1) + [cond.shape[-1]]).expand(*lead, cond.shape[-1])
+        cw = (bott.shape[1] + cond.shape[-1] + 31) // 32 * 32
+        rc = torch.zeros((n, cw), dtype=torch.float32, device=h.device)
+        rc[:, :bott.shape[1]] = bott
+        rc[:, bott.shape[1]:bott.shape[1] + cond.shape[-1]] = cond.reshape(n, -1)
+        rl = self.mlp.rgb_layer
+        hid = linear_rows(rc, packed_linear(rl.hidden_layers[0], pad_in_to=cw), relu=1)
+        rgb = F.linear(hid, rl.output_layer.weight, rl.output_layer.bias)
+        return torch.sigmoid(rgb).view(*lead, 3), F.relu(raw_sigma).view(*lead, 1)
+
     def forward(self, x, condition=None, features=None):
+        if (not torch.is_grad_enabled() and x.is_cuda and condition is not None and features is not None and self.hip_trunk_ok()
+                and hasattr(self.mlp, "bottleneck_layer") and len(self.mlp.rgb_layer.hidden_layers) == 1
+                and len(self.mlp.bottleneck_layer.hidden_layers) == 0 and self.mlp.rgb_layer.hidden_layers[0].out_features % 32 == 0):
+            return self.forward_rows_hip(x, condition, features)
         x = self.posi_encoder(x)
         if condition is not None:
             condition = self.view_encoder(condition)

@@ -191,3 +191,24 @@ def test_render_testing_chunks_equal_one_pass(device):
     torch.testing.assert_close(ret["outputs_coarse"]["rgb"].view(-1, 3), one["outputs_coarse"]["rgb"], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(ret["outputs_coarse"]["depth"].view(-1), one["outputs_coarse"]["depth"], rtol=1e-5, atol=1e-6)
     assert ret["gt_rgb"].shape == (t_views, hh, ww, 3) and ret["gt_depth"].shape == (t_views, hh, ww, 1)
+
+
+def test_ray_branch_mlp_on_matrix_cores_matches_library_forward(device):
+    """A10 at inference: VanillaNeRFRadianceField.forward takes the hand-written MFMA path (1x1 convolutions over the sample
+    rows) and matches the library Linear layers (nerf_mlp.py:146-161,229-234)."""
+    from nerfdet_amd.radiance_field import VanillaNeRFRadianceField
+    torch.manual_seed(2)
+    mlp = VanillaNeRFRadianceField(net_depth=4, net_width=256, skip_layer=3, feature_dim=70, net_depth_condition=1,
+                                   net_width_condition=128).to(device).eval()
+    pts = torch.randn(96, 40, 3, device=device) * 2.0
+    dirs = torch.randn(96, 3, device=device)
+    feat = torch.randn(96, 40, 70, device=device)
+    with torch.no_grad():
+        rgb1, sig1 = mlp(pts, dirs, feat)                      # no grad, GPU -> forward_rows_hip
+        rgb1b, sig1b = mlp.forward_rows_hip(pts, dirs, feat)
+    with torch.enable_grad():
+        rgb0, sig0 = mlp(pts, dirs, feat)                      # library path
+    assert torch.equal(rgb1, rgb1b) and torch.equal(sig1, sig1b)
+    assert rgb1.shape == rgb0.shape and sig1.shape == sig0.shape
+    torch.testing.assert_close(rgb1, rgb0.detach(), rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(sig1, sig0.detach(), rtol=1e-4, atol=2e-5)
