@@ -119,7 +119,34 @@ class ResNet(nn.Module):
         bn_frozen = not any(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
         if x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and bn_frozen and self.use_hip:
             return self.forward_hip(x)
+        if (x.is_cuda and x.dtype == torch.float32 and self.use_hip and self.frozen_stages >= 1 and not x.requires_grad
+                and self._frozen_prefix_in_eval()):
+            return self.forward_frozen_prefix(x)
         return self.forward_library(x)
+
+    def _frozen_prefix_in_eval(self) -> bool:
+        mods = [self.bn1] + [m for i in range(1, self.frozen_stages + 1) for m in getattr(self, f"layer{i}").modules()
+                             if isinstance(m, nn.BatchNorm2d)]
+        return not any(m.training for m in mods)
+
+    def forward_frozen_prefix(self, x):
+        """Training: the frozen stem and stages (``frozen_stages``, eval-mode BatchNorm, no parameter gradients, no gradient
+        into the images) run on the fused inference kernels without autograd bookkeeping; the trainable stages follow on the
+        library modules."""
+        outs = []
+        with torch.no_grad():
+            y = bn_relu_maxpool_nhwc(_nhwc(self.conv1(x)), self.bn1)
+            for i in range(self.frozen_stages):
+                for blk in getattr(self, f"layer{i + 1}"):
+                    y = blk.forward_nhwc(y)
+                if i in self.out_indices:
+                    outs.append(y.permute(0, 3, 1, 2))
+            y = y.permute(0, 3, 1, 2)   # logical NCHW on channels-last memory: what the library convolutions like best
+        for i in range(self.frozen_stages, self.num_stages):
+            y = getattr(self, f"layer{i + 1}")(y)
+            if i in self.out_indices:
+                outs.append(y)
+        return tuple(outs)
 
     use_hip = True  # inference on the GPU: bottlenecks through the fused MFMA convolution (csrc/conv3d_kernels.hip)
 
