@@ -1,0 +1,48 @@
+"""Host-side logic that needs no GPU: the convolution tiling tables / heuristics and the bench's bookkeeping."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tiling_tables_and_heuristics_are_well_formed():
+    from nerfdet_amd import conv3d
+    from nerfdet_amd.conv_tuning import TUNED, TUNED_SPLIT
+    f32_tiles, split_tiles = {64, 128}, {64, 128, 12864, 128256, 3128, 3256, 3257}
+    for table, tiles in ((TUNED, f32_tiles), (TUNED_SPLIT, split_tiles)):
+        assert len(table) >= 20
+        for (m, cout, k_iters, tr), (tile, splits) in table.items():
+            assert m > 0 and cout > 0 and k_iters > 0 and tr in (0, 1)
+            assert tile in tiles and 1 <= splits <= 32 and splits <= k_iters
+            assert not (tr and splits != 1), "transposed convolutions never split K"
+            assert not (tr and tile in (3128, 3256, 3257)), "halo tiles are for stride-1 same-padded layers only"
+    # every (arithmetic, tile) the tables can select has a kernel name for the bench's per-kernel roofline
+    for t in split_tiles:
+        assert ("bf16x3", t) in conv3d.KERNEL_NAMES
+    for t in f32_tiles:
+        assert ("f32", t) in conv3d.KERNEL_NAMES
+    # shapes outside the tables: the heuristic returns something launchable
+    for m in (400, 3200, 25600, 48000, 240000, 2_000_000):
+        for cout in (25, 64, 128, 256, 1024):
+            for k_iters in (2, 8, 72, 216, 864):
+                for halo_ok in (False, True):
+                    tile, splits = conv3d.choose_tiling_split(m + 1, cout, k_iters, halo_ok=halo_ok)   # +1: never a table key
+                    assert tile in split_tiles and 1 <= splits <= min(32, k_iters)
+                    assert halo_ok or tile not in (3128, 3256, 3257)
+                tile, splits = conv3d.choose_tiling(m + 1, cout, k_iters)
+                assert tile in f32_tiles and 1 <= splits <= min(8, k_iters)
+
+
+def test_bench_bookkeeping():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    w = bench.WORKLOADS["cfg2"]
+    assert (w["n_views"], w["img_hw"], w["n_voxels"]) == (50, (240, 320), (40, 40, 16))
+    # every FPN feature row once + (C fp32 + int64 count) per voxel
+    assert bench.k1_algorithmic_bytes(w) == 50 * 256 * 60 * 80 * 4 + (256 * 4 + 8) * 25600 == 272179200
+    traffic, src = bench.k1_measured_traffic("cfg2")
+    assert traffic is not None and traffic > bench.k1_algorithmic_bytes(w) and src.startswith("profiles/")
+    batch = bench.synth_batch(bench.WORKLOADS["tiny"], 3)
+    assert batch["img"].shape == (1, 6, 3, 64, 96) and len(batch["img_metas"][0]["lidar2img"]["extrinsic"]) == 6
+    assert bench.HBM_PEAK_GBS == 8000.0 and bench.MFMA_BF16_PEAK_TFLOPS == 2500.0 and bench.MFMA_F32_PEAK_TFLOPS == 157.3
