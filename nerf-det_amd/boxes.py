@@ -47,5 +47,13 @@ class DepthInstance3DBoxes:
 
 
 def bbox3d2result(bboxes, scores, labels):
-    """mmdet3d/core/bbox/transforms.py:49-67: results live on the CPU."""
+    """mmdet3d/core/bbox/transforms.py:49-67: results live on the CPU.  From the GPU they travel as ONE device-to-host copy (three
+    separate copies are three stream synchronisations at the end of every scene); class ids are exact in fp32."""
+    t = bboxes.tensor
+    if t.is_cuda and scores.is_cuda and labels.is_cuda and t.dtype == torch.float32 and scores.dtype == torch.float32 and t.dim() == 2:
+        k, c = t.shape
+        packed = torch.cat([t, scores.reshape(k, 1), labels.reshape(k, 1).to(torch.float32)], dim=1).cpu()
+        out = object.__new__(type(bboxes))
+        out.tensor, out.box_dim, out.with_yaw = packed[:, :c].contiguous(), bboxes.box_dim, bboxes.with_yaw
+        return dict(boxes_3d=out, scores_3d=packed[:, c].contiguous(), labels_3d=packed[:, c + 1].to(torch.int64))
     return dict(boxes_3d=bboxes.to("cpu"), scores_3d=scores.cpu(), labels_3d=labels.cpu())
