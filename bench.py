@@ -2,28 +2,31 @@
 """Headline benchmark: scenes/s of NeRF-Det inference on BASELINE.json configs[1]
 (nerfdet_res50_2x_low_res, 50 views 240x320, 40x40x16 voxels, fp32, 1 scene per step per GPU).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: spawns its N ranks itself (one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # or under an external launcher (RANK / WORLD_SIZE in the env)
 
-A step is one full ``nerfdet.forward_test`` on one synthetic scene: ResNet-50 + FPN (PyTorch-ROCm / MIOpen), the
-hand-written HIP hot path (projection, gather, multi-view aggregation, density MLP gating), the 3D neck + head,
-box decoding and HIP NMS, results copied to the host as the reference does.  Nothing is skipped or cached
-between steps.  Inputs are resident in HBM when the timed region starts.
+A step is one full ``nerfdet.forward_test`` -- literally ``det(return_loss=False, **batch)`` -- on one synthetic scene:
+ResNet-50 + FPN, the hand-written HIP hot path (projection, gather, multi-view aggregation, density MLP gating), the 3D neck +
+head, box decoding and HIP NMS, results copied to the host as the reference does.  Nothing is skipped or cached between
+steps.  Inputs are resident in HBM when the timed region starts.
 
-One process per GPU.  Scenes are independent units, so N ranks run N scene streams with no data-path collective
-(weak scaling); the only collectives are the timing barrier and the max-over-ranks of the elapsed time.
-Rank 0 prints ONE JSON line; `roofline` is for the dominant hand-written kernel of the step (the convolution instantiation
-with the largest share: its algorithmic FLOPs / its event-timed launches, against the matrix-core peak of its arithmetic),
-`roofline_all_convolutions` aggregates every convolution launch, `roofline_projection` is the fused backproject+aggregate
-kernel of the volumetric path against HBM; all timed with events on the stream the kernels are launched on, inside the
-timed region.
+One process per GPU.  Scenes are independent units, so N ranks run N scene streams with no data-path collective (weak
+scaling); the only collectives are the timing barrier and the max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+Per-kernel figures come from event pairs the product path records on its launch stream while the timed steps run
+(nerfdet_amd/trace.py): `roofline` = the dominant hand-written kernel of the step (the convolution instantiation with the largest
+share) against the matrix-core peak of its arithmetic; `roofline_all_convolutions` aggregates every convolution launch;
+`roofline_memory_bound_convolutions` prices the launches whose arithmetic intensity lies below the machine's ridge point (the
+ResNet 1x1 layers) against HBM instead; `roofline_projection` / `roofline_density_features` are the gather kernels K1 / K2
+of the volumetric path against HBM.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,10 +40,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA peak (v_mfma_f32_16x16x4_f32), = fp32 vector peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
+# BASELINE.json configs; cfg5's voxel size is halved so that the 80x80x32 grid keeps the room's extent ("state which")
 WORKLOADS = {
     "cfg2": dict(n_views=50, img_hw=(240, 320), channels=256, n_voxels=(40, 40, 16), voxel_size=(0.16, 0.16, 0.2), depth=50),
     "cfg1": dict(n_views=10, img_hw=(240, 320), channels=256, n_voxels=(40, 40, 16), voxel_size=(0.16, 0.16, 0.2), depth=50),
-    "cfg5": dict(n_views=101, img_hw=(240, 320), channels=256, n_voxels=(80, 80, 32), voxel_size=(0.08, 0.08, 0.1), depth=50),
+    "cfg5": dict(n_views=101, img_hw=(320, 480), channels=256, n_voxels=(80, 80, 32), voxel_size=(0.08, 0.08, 0.1), depth=101),
     "tiny": dict(n_views=6, img_hw=(64, 96), channels=256, n_voxels=(16, 16, 8), voxel_size=(0.4, 0.4, 0.4), depth=50),
 }
 
@@ -52,19 +56,30 @@ def k1_algorithmic_bytes(w):
     return w["n_views"] * w["channels"] * hf * wf * 4 + (w["channels"] * 4 + 8) * n
 
 
-def k1_measured_traffic(workload):
-    """HBM-side bytes per K1 launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled as the
-    gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE); None when no profile matches the workload."""
+def k2_algorithmic_bytes(w, cm=32):
+    """de-normalised images + mapped map read once + 2*(3+cm) floats written per voxel."""
+    n = w["n_voxels"][0] * w["n_voxels"][1] * w["n_voxels"][2]
+    h, wd = w["img_hw"]
+    return 4 * (w["n_views"] * 3 * h * wd + w["n_views"] * cm * (h // 4) * (wd // 4) + 2 * (3 + cm) * n)
+
+
+def measured_traffic(workload):
+    """HBM-side bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE in separate
+    passes, FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes): {kernel-name prefix: bytes}, source file."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), reverse=True):  # newest round first
         try:
             with open(path) as f:
                 d = json.load(f)
-            if d.get("workload") == workload:
-                return int(d["k1"]["traffic_bytes"]), os.path.relpath(path, ROOT)
+            if d.get("workload") != workload:
+                continue
+            out = {"k_backproject_aggregate": int(d["k1"]["traffic_bytes"])}
+            for name, v in d.get("kernels", {}).items():
+                out[name] = int(v["traffic_bytes"])
+            return out, os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError):
             pass
-    return None, None
+    return {}, None
 
 
 def synth_batch(w, seed):
@@ -106,10 +121,10 @@ def to_device(batch, device):
     return out
 
 
-def cpu_baseline(w, det_cpu, batch, scenes=2):
-    """The reference's algorithm on the host cores: the oracle (PyTorch-CPU restatement: materialised per-view
-    volume, Python per-view loops, sequential NMS) for the volumetric path, 3D neck, head and NMS, plus the same
-    ResNet-50+FPN modules run by PyTorch-CPU."""
+def cpu_baseline(w, det_cpu, batch, scenes=5, warmups=2):
+    """The reference's algorithm on the host cores (median of >= 5 runs after 2 warm-ups, per stage):
+    the oracle (PyTorch-CPU restatement: materialised per-view volume, Python per-view loops, sequential NMS) for the
+    volumetric path, 3D neck, head and NMS, plus the same ResNet+FPN modules run by PyTorch-CPU."""
     from oracle import nerfdet_oracle as O
     cores = min(os.cpu_count() or 1, 32)  # measured on the GPU box: 16-32 threads is the knee (256 is 50x slower)
     torch.set_num_threads(cores)
@@ -118,22 +133,83 @@ def cpu_baseline(w, det_cpu, batch, scenes=2):
     sd_mlp = det_cpu.nerf_mlp.state_dict()
     sd_n3 = dict(det_cpu.neck_3d.state_dict())
     sd_head = det_cpu.bbox_head.state_dict()
-    times = []
+    rows = []
     with torch.no_grad():
-        for _ in range(scenes + 1):
-            t0 = time.perf_counter()
+        for _ in range(scenes + warmups):
+            t = [time.perf_counter()]
             feats = det_cpu.neck(det_cpu.backbone(batch["img"][0]))[0]
+            t.append(time.perf_counter())
             ov = O.extract_volume(feats, batch["denorm_images"][0], meta, w["n_voxels"], w["voxel_size"],
                                   det_cpu.mapping[0].weight, det_cpu.mapping[0].bias, sd_mlp)
+            t.append(time.perf_counter())
             n3 = O.neck3d_forward(sd_n3, ov["volume"].unsqueeze(0))
+            t.append(time.perf_counter())
             ctr, reg, cls = O.head_forward(sd_head, n3)
             O.head_get_bboxes(ctr, reg, cls, ov["valid"].unsqueeze(0).float(), meta["lidar2img"]["origin"], w["voxel_size"],
                               tc.nms_pre, tc.score_thr, tc.iou_thr)
-            times.append(time.perf_counter() - t0)
-    t = sorted(times[1:])[len(times[1:]) // 2]
-    return dict(value=1.0 / t, unit="scenes/s", cores=cores, kind="port",
-                sample=f"{scenes} full scenes after 1 warm-up (median {t:.2f} s/scene): ResNet-50+FPN (PyTorch-CPU) + oracle "
-                       f"volumetric path + 3D neck + head + sequential NMS, same shapes and weights, fp32")
+            t.append(time.perf_counter())
+            rows.append([b - a for a, b in zip(t, t[1:])] + [t[-1] - t[0]])
+    rows = rows[warmups:]
+    med = [sorted(r[i] for r in rows)[len(rows) // 2] for i in range(5)]
+    return dict(value=1.0 / med[4], unit="scenes/s", cores=cores, kind="port",
+                sample=f"median of {scenes} full scenes after {warmups} warm-ups ({med[4]:.2f} s/scene): ResNet-{w['depth']}+FPN (PyTorch-CPU) + "
+                       f"oracle volumetric path + 3D neck + head + sequential NMS, same shapes and weights, fp32",
+                stages_s=dict(backbone_fpn=med[0], volumetric_hot_path=med[1], neck3d=med[2], head_nms=med[3]))
+
+
+def launch_ranks(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as fresh child processes (this parent never touches the
+    GPU), rank 0 inherits stdout and prints the JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in procs:      # a rank died: the others would wait in the barrier forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            p.kill()
+    return rc
+
+
+def dry_run(args, rank, world):
+    """Launcher / rendezvous / timing plumbing without a GPU (tests/test_dist_cpu.py): gloo, a sleep as the step."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (rank + 1))   # ranks differ: the job's time must be the slowest rank's
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    from nerfdet_amd.dist import max_over_ranks
+    dt = max_over_ranks(dt)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "value": world * args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "dry_run": True}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -148,105 +224,50 @@ def main():
                          "launches within 1 %% on MI355X: the step is GPU-bound, launch-ahead already hides the gaps")
     ap.add_argument("--conv-arithmetic", default=None, choices=["f32", "bf16x3"],
                     help="convolution kernel family (default: the package default, nerfdet_amd.conv3d.ARITHMETIC)")
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.dry_run:
+        return dry_run(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    import nerfdet_amd.volume as V
+    import nerfdet_amd.conv3d as C3
+    from nerfdet_amd import trace
     w = WORKLOADS[args.workload]
     det = build_model(w)
     batch_cpu = synth_batch(w, rank)
     det_gpu = det.to(device)
     batch = to_device(batch_cpu, device)
-
-    # event pairs around the dominant hand-written kernel and around the stages, all on torch's current stream,
-    # which is the stream the C ABI launches on
-    k1_events, stage_events = [], {"backbone_fpn": [], "volumetric_hot_path": [], "neck3d": [], "head_nms": []}
-    orig_k1 = V.ops.backproject_aggregate
-    record = {"on": False, "step": 0}
-
-    def ev():
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        return e
-
-    def timed_k1(*a, **k):
-        if not record["on"]:
-            return orig_k1(*a, **k)
-        e0 = ev()
-        r = orig_k1(*a, **k)
-        k1_events.append((e0, ev()))
-        return r
-    V.ops.backproject_aggregate = timed_k1
-
-    # every launch of the MFMA convolution (the dominant kernel of the step: 3D neck/head + ResNet/FPN bottlenecks)
-    import nerfdet_amd.conv3d as C3
     if args.conv_arithmetic:
         C3.set_arithmetic(args.conv_arithmetic)
-    conv_events = []
 
-    def conv_hook(flops, thunk, kernel_name=""):
-        # 150 event records per step cost ~2 % of the step: sample every 4th timed step (still inside the timed region)
-        if not record["on"] or record["step"] % 4 != 0:
-            return thunk()
-        e0 = ev()
-        r = thunk()
-        conv_events.append((flops, e0, ev(), kernel_name))
-        return r
-    C3.launch_hook = conv_hook
+    state = {"step": 0}
+    # ~150 conv launches per step: their event pairs cost ~2 % of the step, so they are sampled on every 4th timed step; the two
+    # gather kernels and the five stage marks are recorded on every step
+    rec = trace.Recorder(sample=lambda name: (not name.startswith(("k_conv", "f32:", "bf16x3:"))) or state["step"] % 4 == 0)
 
-    from nerfdet_amd.graphed import GraphedForwardTest
-    graphed = GraphedForwardTest(det_gpu)
+    if args.graph:
+        from nerfdet_amd.graphed import GraphedForwardTest
+        graphed = GraphedForwardTest(det_gpu)
+        graphed.k1_hook = lambda fn: trace.span("k_backproject_aggregate", fn, bytes=k1_algorithmic_bytes(w), kind="hbm")
 
-    def k1_hook(fn):
-        if not record["on"]:
-            return fn()
-        e0 = ev()
-        r = fn()
-        k1_events.append((e0, ev()))
-        return r
-    graphed.k1_hook = k1_hook
-
-    def step_graph():
-        """nerfdet.forward_test with the static part replayed from two hipGraphs; the aggregation kernel is launched
-        eagerly between them, bracketed by events."""
-        return graphed(return_loss=False, **batch)
-
-    def step_eager():
-        """= nerfdet.forward_test (simple_test), with event markers between its stages when recording."""
-        with torch.no_grad():
-            if not record["on"]:
+        def step():
+            return graphed(return_loss=False, **batch)
+    else:
+        def step():
+            with torch.no_grad():
                 return det_gpu(return_loss=False, **batch)
-            rb = det_gpu._ray_batch(batch)
-            e0 = ev()
-            x, b, stride = det_gpu.extract_2d(batch["img"])
-            e1 = ev()
-            # as nerfdet.extract_feat does: per-scene constants computed on the host behind the backbone queue, async upload
-            geom = V.scene_geometry(batch["img_metas"][0], det_gpu.n_voxels, det_gpu.voxel_size, stride, device)
-            out = V.extract_volume(x, rb["denorm_images"][0], batch["img_metas"][0], det_gpu.n_voxels, det_gpu.voxel_size,
-                                   det_gpu.mapping, det_gpu.nerf_mlp, stride=stride, channels_last_out=True, geometry=geom)
-            e2 = ev()
-            x3 = det_gpu.neck_3d(out["volume"].unsqueeze(0))
-            e3 = ev()
-            from nerfdet_amd.boxes import DepthInstance3DBoxes, bbox3d2result
-            batch["img_metas"][0].setdefault("box_type_3d", DepthInstance3DBoxes)
-            boxes = det_gpu.bbox_head.simple_test_fused(x3, out["valid"].unsqueeze(0).float(), batch["img_metas"])
-            res = [bbox3d2result(*bx) for bx in boxes]
-            e4 = ev()
-            for name, a, c in (("backbone_fpn", e0, e1), ("volumetric_hot_path", e1, e2), ("neck3d", e2, e3), ("head_nms", e3, e4)):
-                stage_events[name].append((a, c))
-            return res
-
-    step = step_graph if args.graph else step_eager
 
     def barrier():
         if world > 1:
@@ -254,59 +275,71 @@ def main():
 
     for _ in range(args.warmup):
         res = step()
-    record["on"] = True
+    trace.recorder = rec
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        record["step"] = i
+        state["step"] = i
         res = step()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    from nerfdet_amd.dist import max_over_ranks
+    dt = max_over_ranks(dt, device)
 
-    if args.graph:  # stage breakdown from a few eager steps outside the timed region (events cannot sit inside a graph)
-        n_k1 = len(k1_events)
-        for _ in range(5):
-            record["step"] = 0   # sample the per-launch conv events on each of these
-            step_eager()
-        torch.cuda.synchronize()
-        del k1_events[n_k1:]
-    k1_ms = sorted(a.elapsed_time(b) for a, b in k1_events)
-    k1_avg_ms = sum(k1_ms) / len(k1_ms)
-    if C3.ARITHMETIC == "bf16x3":
-        conv_kernel = ("k_conv_split (implicit-GEMM convolution on the bf16 matrix cores, fp32 operands split exactly into 3 bf16 terms, "
-                       "6 MFMA products per multiply, fp32 accumulate: 3D neck + head, ResNet/FPN; all tile instantiations, split-K "
-                       "reduce launches included in the event spans)")
-        conv_peak = MFMA_BF16_PEAK_TFLOPS / 6.0
-        conv_peak_note = ("achieved = algorithmic fp32 convolution FLOPs / time; peak = dense bf16 MFMA peak 2500 TFLOP/s / 6 issued "
-                          "products per algorithmic multiply-add")
-    else:
-        conv_kernel = ("k_conv3d_igemm (fp32-MFMA implicit-GEMM convolution: 3D neck + head, ResNet/FPN bottlenecks; both tile "
-                       "instantiations, split-K reduce launches included in the event spans)")
-        conv_peak = MFMA_F32_PEAK_TFLOPS
-        conv_peak_note = "dense fp32-input MFMA peak"
-    abytes = k1_algorithmic_bytes(w)
-    k1_traffic, k1_traffic_src = k1_measured_traffic(args.workload)
-    achieved = abytes / (k1_avg_ms * 1e-3) / 1e9
-    stages = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in stage_events.items()}
-    conv_ms = [a.elapsed_time(b) for _, a, b, _ in conv_events]
-    conv_flops = sum(f for f, _, _, _ in conv_events)
-    conv_tflops = conv_flops / (sum(conv_ms) * 1e-3) / 1e12
-    n_conv_steps = max(1, len({i for i in range(args.steps) if i % 4 == 0}) if not args.graph else 5)
-    # the dominant single kernel: the instantiation with the largest share of the step
-    by_kernel = {}
-    for (f, _, _, name), ms in zip(conv_events, conv_ms):
-        g = by_kernel.setdefault(name, [0.0, 0.0, 0])
-        g[0] += f; g[1] += ms; g[2] += 1
-    dom_name, (dom_flops, dom_ms, dom_n) = max(by_kernel.items(), key=lambda kv: kv[1][1])
-    dom_tflops = dom_flops / (dom_ms * 1e-3) / 1e12
+    n_conv_steps = len([i for i in range(args.steps) if i % 4 == 0])
+    if args.graph:  # per-kernel breakdown from a few eager steps outside the timed region (events cannot sit inside a graph)
+        keep = [s for s in rec.spans if s[0] == "k_backproject_aggregate"]
+        rec.spans, rec.marks = [], []
+        state["step"] = 0
+        n_conv_steps = 5
+        with torch.no_grad():
+            for _ in range(n_conv_steps):
+                det_gpu(return_loss=False, **batch)
+        rec.spans = [s for s in rec.spans if s[0] != "k_backproject_aggregate"] + keep
+    trace.recorder = None
+    torch.cuda.synchronize()
 
     if rank == 0:
+        spans = rec.span_ms()
+        stages = rec.stage_ms()
+        traffic, traffic_src = measured_traffic(args.workload)
+        bf16x3 = C3.ARITHMETIC == "bf16x3"
+        if bf16x3:
+            conv_kernel = ("k_conv_split (implicit-GEMM convolution on the bf16 matrix cores, fp32 operands split exactly into 3 bf16 terms, "
+                           "6 MFMA products per multiply, fp32 accumulate: 3D neck + head, ResNet/FPN; all tile instantiations, split-K "
+                           "reduce launches included in the event spans)")
+            conv_peak = MFMA_BF16_PEAK_TFLOPS / 6.0
+            conv_peak_note = ("achieved = algorithmic fp32 convolution FLOPs / time; peak = dense bf16 MFMA peak 2500 TFLOP/s / 6 issued "
+                              "products per algorithmic multiply-add")
+        else:
+            conv_kernel = ("k_conv3d_igemm (fp32-MFMA implicit-GEMM convolution: 3D neck + head, ResNet/FPN bottlenecks; both tile "
+                           "instantiations, split-K reduce launches included in the event spans)")
+            conv_peak = MFMA_F32_PEAK_TFLOPS
+            conv_peak_note = "dense fp32-input MFMA peak"
+        ridge = conv_peak * 1e12 / (HBM_PEAK_GBS * 1e9)     # FLOP per byte where the two roofs meet
+        conv = {k: v for k, v in spans.items() if v and v[0][1].get("kind") == "conv"}
+        by_kernel = {k: [sum(i["flops"] for _, i in v), sum(ms for ms, _ in v), len(v), sum(i["bytes"] for _, i in v)] for k, v in conv.items()}
+        conv_flops = sum(v[0] for v in by_kernel.values())
+        conv_ms = sum(v[1] for v in by_kernel.values())
+        conv_n = sum(v[2] for v in by_kernel.values())
+        dom_name, (dom_flops, dom_ms, dom_n, dom_bytes) = max(by_kernel.items(), key=lambda kv: kv[1][1])
+        dom_tflops = dom_flops / (dom_ms * 1e-3) / 1e12
+        mem = [(ms, i) for v in conv.values() for ms, i in v if i["flops"] / max(i["bytes"], 1) < ridge]
+        mem_bytes, mem_ms = sum(i["bytes"] for _, i in mem), sum(ms for ms, _ in mem)
+
+        def hbm_line(name, label, abytes):
+            ms = sorted(m for m, _ in spans.get(name, []))
+            if not ms:
+                return None
+            avg = sum(ms) / len(ms)
+            ach = abytes / (avg * 1e-3) / 1e9
+            return {"kernel": label, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": traffic.get(name), "traffic_source": None if traffic.get(name) is None else
+                    f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                    "algorithmic_bytes": abytes, "avg_launch_ms": avg, "median_launch_ms": ms[len(ms) // 2], "launches": len(ms)}
+
         out = {
             "metric": f"scenes/sec ({w['n_views']}-view {w['img_hw'][0]}x{w['img_hw'][1]}, {'x'.join(map(str, w['n_voxels']))} voxels)",
             "value": world * args.steps / dt,
@@ -318,7 +351,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if C3.ARITHMETIC == "f32" else "f32 (convolutions: fp32 operands as exact 3-term bf16 sums on the bf16 MFMA, fp32 accumulate)",
+            "dtype": "f32" if not bf16x3 else "f32 (convolutions: fp32 operands as exact 3-term bf16 sums on the bf16 MFMA, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: nerfdet_res{w['depth']}_2x_low_res forward_test, {w['n_views']} views "
                                    f"{w['img_hw'][0]}x{w['img_hw'][1]}, {'x'.join(map(str, w['n_voxels']))} voxels, fp32, "
@@ -327,23 +360,31 @@ def main():
             "roofline": {"kernel": f"{dom_name} (the convolution instantiation with the largest share of the step; event spans include the "
                                    f"split-K reduce launch where a layer splits K)",
                          "bound": "mfma", "achieved": dom_tflops, "peak": conv_peak, "unit": "TFLOP/s",
-                         "frac": dom_tflops / conv_peak, "traffic": None, "peak_note": conv_peak_note,
-                         "algorithmic_flops_per_launch": dom_flops / dom_n, "launches_per_step": dom_n / n_conv_steps,
+                         "frac": dom_tflops / conv_peak, "traffic": traffic.get(dom_name),
+                         "traffic_source": None if traffic.get(dom_name) is None else traffic_src, "peak_note": conv_peak_note,
+                         "algorithmic_flops_per_launch": dom_flops / dom_n, "algorithmic_bytes_per_launch": dom_bytes / dom_n,
+                         "launches_per_step": dom_n / n_conv_steps,
                          "avg_launch_ms": dom_ms / dom_n, "total_ms_per_step": dom_ms / n_conv_steps, "sampled_steps": n_conv_steps},
             "roofline_all_convolutions": {"kernel": conv_kernel,
-                         "bound": "mfma", "achieved": conv_tflops, "peak": conv_peak, "unit": "TFLOP/s",
-                         "frac": conv_tflops / conv_peak, "traffic": None, "peak_note": conv_peak_note,
-                         "algorithmic_flops_per_step": conv_flops / n_conv_steps, "launches_per_step": len(conv_events) / n_conv_steps,
-                         "avg_launch_ms": sum(conv_ms) / len(conv_ms), "total_ms_per_step": sum(conv_ms) / n_conv_steps,
+                         "bound": "mfma", "achieved": conv_flops / (conv_ms * 1e-3) / 1e12, "peak": conv_peak, "unit": "TFLOP/s",
+                         "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / conv_peak, "traffic": None, "peak_note": conv_peak_note,
+                         "algorithmic_flops_per_step": conv_flops / n_conv_steps, "launches_per_step": conv_n / n_conv_steps,
+                         "avg_launch_ms": conv_ms / conv_n, "total_ms_per_step": conv_ms / n_conv_steps,
                          "sampled_steps": n_conv_steps,
                          "per_kernel": {k: {"launches_per_step": v[2] / n_conv_steps, "avg_launch_ms": v[1] / v[2],
-                                            "tflops": v[0] / (v[1] * 1e-3) / 1e12} for k, v in sorted(by_kernel.items())}},
-            "roofline_projection": {"kernel": "k_backproject_aggregate (fused backproject + view mean/count + alpha gating)",
-                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": k1_traffic,
-                         "traffic_source": f"{k1_traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                         "algorithmic_bytes": abytes,
-                         "avg_launch_ms": k1_avg_ms, "median_launch_ms": k1_ms[len(k1_ms) // 2]},
+                                            "tflops": v[0] / (v[1] * 1e-3) / 1e12, "gbytes_per_s": v[3] / (v[1] * 1e-3) / 1e9}
+                                        for k, v in sorted(by_kernel.items())}},
+            "roofline_memory_bound_convolutions": None if not mem else {
+                         "kernel": f"convolution launches whose algorithmic intensity is below the ridge point ({ridge:.0f} FLOP/B): the ResNet "
+                                   f"1x1 layers and the stride-2 / small-K layers -- HBM is the roof that binds them",
+                         "bound": "hbm", "achieved": mem_bytes / (mem_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": mem_bytes / (mem_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_step": mem_bytes / n_conv_steps, "launches_per_step": len(mem) / n_conv_steps,
+                         "total_ms_per_step": mem_ms / n_conv_steps},
+            "roofline_projection": hbm_line("k_backproject_aggregate", "k_backproject_aggregate (K1: fused backproject + view mean/count + alpha gating)",
+                                            k1_algorithmic_bytes(w)),
+            "roofline_density_features": hbm_line("k_density_features", "k_density_features (K2: mapped features + RGB -> per-voxel mean / exp(-var) rows)",
+                                                  k2_algorithmic_bytes(w)),
             "execution": "hipGraph replay (2 graphs) + eager K1 + eager post-processing" if args.graph else "eager launches",
             "stages_ms": stages,
             "detections_last_step": int(len(res[0]["scores_3d"])),

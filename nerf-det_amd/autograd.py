@@ -19,6 +19,15 @@ def _stream(t):
     return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+def _dense_nhwc(t):
+    """Logical (n,C,h,w) channels-last tensor whose (n,h,w,C) memory is DENSE.  The backward kernels walk the saved input and
+    the gradient buffer with one index, so both must share their pitches; an [:h,:w] crop of a padded map (real ScanNet frames:
+    59 of 60 feature rows) is copied once here."""
+    f = ops.to_channels_last(t)
+    rows = f.permute(0, 2, 3, 1)
+    return f if rows.is_contiguous() else rows.contiguous().permute(0, 3, 1, 2)
+
+
 class BackprojectMean(torch.autograd.Function):
     """features (n_v,C,h,w) -> (mean (C,X,Y,Z), count (1,X,Y,Z)); nerfdet.py:164-176."""
 
@@ -55,7 +64,7 @@ class DensityFeatures(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mapped, bias, denorm_images, points, projection, rgb_projection):
-        m = ops.to_channels_last(mapped.detach())
+        m = _dense_nhwc(mapped.detach())
         out = ops.density_features(m, bias.detach(), denorm_images, points, projection, rgb_projection)
         ctx.save_for_backward(m, bias.detach(), points, projection)
         return out
@@ -67,11 +76,11 @@ class DensityFeatures(torch.autograd.Function):
         n = points[0].numel()
         g = g.float().contiguous()
         dm = torch.zeros((n_v, h, w, cm), dtype=torch.float32, device=g.device)
+        assert (m.stride(0), m.stride(2)) == (dm.stride(0), dm.stride(1)), "saved input and gradient buffer must share their pitches"
         db = torch.zeros((cm,), dtype=torch.float32, device=g.device)
         check(_lib.load().ndet_density_features_bwd(_ptr(g), _ptr(m), n_v, cm, h, w, m.stride(0), m.stride(2), _ptr(bias.float().contiguous()),
                                                     _ptr(points.float().contiguous()), n, _ptr(projection.float().contiguous()), _ptr(dm),
                                                     _ptr(db), _stream(g)), "density_features_bwd")
-        # m may be a strided channels-last view (cropped map): dm is dense (n_v,h,w,cm) with the same logical shape
         return dm.permute(0, 3, 1, 2), db, None, None, None, None
 
 
@@ -81,7 +90,7 @@ class RayViewStats(torch.autograd.Function):
     @staticmethod
     def forward(ctx, featmaps, xyz, train_imgs, train_cameras):
         from . import rays
-        f = ops.to_channels_last(featmaps.detach())
+        f = _dense_nhwc(featmaps.detach())
         glob, pm, vc = rays.ray_view_stats(xyz, train_imgs, train_cameras, f)
         cams = train_cameras.squeeze(0) if train_cameras.dim() == 3 else train_cameras
         ke, h, w = rays._camera_matrices(cams)
@@ -96,6 +105,7 @@ class RayViewStats(torch.autograd.Function):
         n_v, d, hf, wf = f.shape
         g = g.float().reshape(pts.shape[0], -1).contiguous()
         df = torch.zeros((n_v, hf, wf, d), dtype=torch.float32, device=g.device)
+        assert (f.stride(0), f.stride(2)) == (df.stride(0), df.stride(1)), "saved input and gradient buffer must share their pitches"
         check(_lib.load().ndet_ray_view_stats_bwd(_ptr(g), _ptr(pts), pts.shape[0], _ptr(ke), n_v, ctx.hw[0], ctx.hw[1], _ptr(f), d, hf, wf,
                                                   f.stride(0), f.stride(2), _ptr(df), _stream(g)), "ray_view_stats_bwd")
         return df.permute(0, 3, 1, 2), None, None, None

@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, trace
 from ._lib import check
 from .conv_tuning import TUNED, TUNED_SPLIT
 
@@ -39,8 +39,13 @@ KERNEL_NAMES = {("bf16x3", 64): "k_conv_split<64,64,2,2>", ("bf16x3", 128): "k_c
                 ("f32", 64): "k_conv3d_igemm<64,64,2,2>", ("f32", 128): "k_conv3d_igemm<128,128,4,2>"}
 
 
-def _launch(flops, thunk, arith="f32", tile=0):
-    return thunk() if launch_hook is None else launch_hook(flops, thunk, KERNEL_NAMES.get((arith, tile), f"{arith}:{tile}"))
+def _launch(flops, thunk, arith="f32", tile=0, nbytes=0):
+    """Every MFMA-convolution launch goes through here: ``nbytes`` = algorithmic traffic (input + weights + output + residual, each
+    touched once), ``flops`` = algorithmic multiply-adds x 2."""
+    name = KERNEL_NAMES.get((arith, tile), f"{arith}:{tile}")
+    if launch_hook is not None:
+        return launch_hook(flops, thunk, name)
+    return trace.span(name, thunk, flops=flops, bytes=nbytes, kind="conv")
 
 
 def choose_tiling(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 0, transposed: bool = False):
@@ -127,9 +132,10 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
     lib = _lib.load()
     planes = split_planes(pk)
     d, h, w = dims
+    nbytes = 4 * (x.numel() + pk["w"].numel() + out.numel() + (0 if residual is None else residual.numel()))
     _launch(flops, lambda: check(lib.ndet_conv_ndhwc_split(_ptr(x), _ptr(planes), _ptr(out), d, h, w, pk["cin"], pk["cout"], i3(kernel), i3(stride),
                                                           i3(pad), int(transposed), _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual),
-                                                          int(residual_up2), relu, splits, tile, _ptr(ws), st), "conv_ndhwc_split"), "bf16x3", tile)
+                                                          int(residual_up2), relu, splits, tile, _ptr(ws), st), "conv_ndhwc_split"), "bf16x3", tile, nbytes)
     return out
 
 
@@ -250,7 +256,8 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
         ws = torch.empty((int(lib.ndet_conv3d_workspace_bytes(d, h, w, cin, cout, k, s, splits)),), dtype=torch.uint8, device=x.device)
     st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     _launch(flops, lambda: check(lib.ndet_conv3d_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), d, h, w, cin, cout, k, s, int(tr), _ptr(pk["scale"]),
-                                                       _ptr(pk["shift"]), _ptr(residual), relu, splits, tile, _ptr(ws), st), "conv3d_ndhwc"), "f32", tile)
+                                                       _ptr(pk["shift"]), _ptr(residual), relu, splits, tile, _ptr(ws), st), "conv3d_ndhwc"), "f32", tile,
+            4 * (x.numel() + pk["w"].numel() + out.numel() + (0 if residual is None else residual.numel())))
     return out
 
 
@@ -283,7 +290,7 @@ def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = No
     _launch(2 * m * cout * cin * kh * kw,
             lambda: check(lib.ndet_conv_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), n, h, w, cin, cout, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw),
                                               _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), int(residual_up2), relu, splits, tile, _ptr(ws), st),
-                          "conv2d_nhwc"), "f32", tile)
+                          "conv2d_nhwc"), "f32", tile, 4 * (x.numel() + pk["w"].numel() + out.numel() + (0 if residual is None else residual.numel())))
     return out
 
 

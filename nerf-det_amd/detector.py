@@ -6,7 +6,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from . import ops
+from . import ops, trace
 from .boxes import DepthInstance3DBoxes, bbox3d2result
 from .radiance_field import VanillaNeRFRadianceField
 from .registry import DETECTORS, build_backbone, build_head, build_neck
@@ -111,7 +111,9 @@ class nerfdet(BaseDetector):
         assert depth is None, "depth is never forwarded to extract_feat by the reference (SURVEY.md 0.1)"
         assert ray_batch is not None and self.nerf_density and self.nerf_mode == "image", \
             "effective contract of the reference: use_ray=True, nerf_density=True, nerf_mode='image' (SURVEY.md 0.2)"
+        trace.mark("begin")
         x, batch, stride = self.extract_2d(img)
+        trace.mark("backbone_fpn")
         # per-scene constants: host arithmetic while the GPU works through the backbone queue, asynchronous upload
         geoms = None
         if not torch.is_grad_enabled():
@@ -138,7 +140,10 @@ class nerfdet(BaseDetector):
             valids.append(out["valid"])
         x3 = volumes[0].unsqueeze(0) if len(volumes) == 1 else torch.stack(volumes)
         valids = valids[0].unsqueeze(0) if len(valids) == 1 else torch.stack(valids)
-        return self.neck_3d(x3), valids, None, rgb_preds, []
+        trace.mark("volumetric_hot_path")
+        x3 = self.neck_3d(x3)
+        trace.mark("neck3d")
+        return x3, valids, None, rgb_preds, []
 
     @staticmethod
     def _ray_batch(kwargs):
@@ -186,7 +191,9 @@ class nerfdet(BaseDetector):
             bbox_list = self.bbox_head.simple_test_fused(x, valids.float(), img_metas)
         else:
             bbox_list = self.bbox_head.get_bboxes(*self.bbox_head(x), valids.float(), img_metas)
-        return [bbox3d2result(b, s, l) for b, s, l in bbox_list]
+        res = [bbox3d2result(b, s, l) for b, s, l in bbox_list]
+        trace.mark("head_nms")
+        return res
 
     def aug_test(self, imgs, img_metas):
         pass

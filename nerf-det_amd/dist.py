@@ -33,7 +33,10 @@ def shard_indices(n: int, rank: int, world: int) -> List[int]:
     """Scene indices of this rank: ``DistributedSampler(shuffle=False)`` -- round-robin, padded by wrapping so every
     rank runs the same number of steps (the padding is dropped again by :func:`collect_results`)."""
     per = (n + world - 1) // world
-    idx = list(range(n)) + list(range(per * world - n))
+    idx = list(range(n))
+    pad = per * world - n
+    if pad and idx:   # DistributedSampler: repeat the index list as often as needed (n < world included), never leave the range
+        idx += (idx * ((pad + n - 1) // n))[:pad]
     return idx[rank:per * world:world]
 
 

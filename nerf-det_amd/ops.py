@@ -14,7 +14,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, trace
 from ._lib import NDET_LAYOUT_CN, NDET_LAYOUT_NC, check, float3
 
 Tensor = torch.Tensor
@@ -51,11 +51,16 @@ def _upload_async(host: Tensor, device) -> Tensor:
     key = (tuple(host.shape), str(device))
     ring = _STAGING.get(key)
     if ring is None:
-        ring = _STAGING[key] = [[torch.empty(host.shape, dtype=host.dtype).pin_memory() for _ in range(8)], 0]
-    buf = ring[0][ring[1]]
+        ring = _STAGING[key] = [[[torch.empty(host.shape, dtype=host.dtype).pin_memory(), None] for _ in range(8)], 0]
+    slot = ring[0][ring[1]]
     ring[1] = (ring[1] + 1) % len(ring[0])
-    buf.copy_(host)
-    return buf.to(device, non_blocking=True)
+    if slot[1] is not None:
+        slot[1].synchronize()   # the copy that last read this slot (8 uploads ago) must have left the host buffer
+    slot[0].copy_(host)
+    out = slot[0].to(device, non_blocking=True)
+    slot[1] = torch.cuda.Event()
+    slot[1].record(torch.cuda.current_stream(out.device))
+    return out
 
 
 def compute_projection(img_meta: dict, stride: int, device=None) -> Tensor:
@@ -172,9 +177,11 @@ def backproject_aggregate(features: Tensor, points: Tensor, projection: Tensor, 
         else:
             buf = torch.empty((c, gx, gy, gz), dtype=torch.float32, device=f.device)
             out, layout = buf, NDET_LAYOUT_CN
-    check(_lib.load().ndet_backproject_aggregate(_ptr(f), n_v, c, h, w, f.stride(0), f.stride(2), _ptr(points), n,
-                                                 _ptr(projection), _ptr(alpha), _ptr(buf), layout, _ptr(count),
-                                                 _stream(f)), "backproject_aggregate")
+    # algorithmic bytes: every feature row once + (C fp32 + int64 count) per voxel
+    trace.span("k_backproject_aggregate", lambda: check(
+        _lib.load().ndet_backproject_aggregate(_ptr(f), n_v, c, h, w, f.stride(0), f.stride(2), _ptr(points), n, _ptr(projection), _ptr(alpha),
+                                               _ptr(buf), layout, _ptr(count), _stream(f)), "backproject_aggregate"),
+        bytes=4 * n_v * c * h * w + (4 * c + 8) * n, kind="hbm")
     return out, count
 
 
@@ -198,9 +205,12 @@ def density_features(mapped: Tensor, bias: Tensor, denorm_images: Tensor, points
     n = points.shape[-3] * points.shape[-2] * points.shape[-1]
     points, projection, rgb_projection, bias = _f32c(points), _f32c(projection), _f32c(rgb_projection), _f32c(bias)
     out = torch.empty((n, 2 * (3 + cm)), dtype=torch.float32, device=m.device)
-    check(_lib.load().ndet_density_features(_ptr(m), n_v, cm, h, w, m.stride(0), m.stride(2), _ptr(bias), _ptr(rgb), hh, ww,
-                                            rgb.stride(0), rgb.stride(1), rgb.stride(2), _ptr(points), n, _ptr(projection),
-                                            _ptr(rgb_projection), _ptr(out), _stream(m)), "density_features")
+    # algorithmic bytes: images + mapped map read once, 2*(3+cm) floats written per voxel
+    trace.span("k_density_features", lambda: check(
+        _lib.load().ndet_density_features(_ptr(m), n_v, cm, h, w, m.stride(0), m.stride(2), _ptr(bias), _ptr(rgb), hh, ww, rgb.stride(0),
+                                          rgb.stride(1), rgb.stride(2), _ptr(points), n, _ptr(projection), _ptr(rgb_projection), _ptr(out),
+                                          _stream(m)), "density_features"),
+        bytes=4 * (n_v * 3 * hh * ww + n_v * cm * h * w + 2 * (3 + cm) * n), kind="hbm")
     return out
 
 

@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _lib, ops, trace
 from ._lib import check
 
 Tensor = torch.Tensor
@@ -83,9 +83,12 @@ def ray_view_stats(xyz: Tensor, train_imgs: Tensor, train_cameras: Tensor, featm
     glob = torch.empty((n, 2 * (3 + d)), dtype=torch.float32, device=xyz.device)
     pm = torch.empty((n,), dtype=torch.bool, device=xyz.device)
     vc = torch.empty((n,), dtype=torch.int32, device=xyz.device)
-    check(_lib.load().ndet_ray_view_stats(_ptr(pts), n, _ptr(ke), n_v, h, w, _ptr(rgb), rgb.shape[2], rgb.shape[3],
-                                          rgb.stride(0), rgb.stride(1), rgb.stride(2), _ptr(f), d, hf, wf, f.stride(0), f.stride(2),
-                                          _ptr(glob), _ptr(pm), _ptr(vc), _stream(xyz)), "ray_view_stats")
+    # algorithmic bytes: images + mapped map read once, 2*(3+d) floats written per sample
+    trace.span("k_ray_view_stats", lambda: check(
+        _lib.load().ndet_ray_view_stats(_ptr(pts), n, _ptr(ke), n_v, h, w, _ptr(rgb), rgb.shape[2], rgb.shape[3], rgb.stride(0), rgb.stride(1),
+                                        rgb.stride(2), _ptr(f), d, hf, wf, f.stride(0), f.stride(2), _ptr(glob), _ptr(pm), _ptr(vc),
+                                        _stream(xyz)), "ray_view_stats"),
+        bytes=4 * (n_v * 3 * rgb.shape[2] * rgb.shape[3] + n_v * d * hf * wf + 2 * (3 + d) * n), kind="hbm")
     return glob.view(*shape, -1), pm.view(*shape), vc.view(*shape)
 
 

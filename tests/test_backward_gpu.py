@@ -183,3 +183,43 @@ def test_detector_train_step(device):
         opt.step()
         losses.append(out["log_vars"]["loss"])
     assert losses[-1] < losses[0], losses
+
+
+def test_backward_through_cropped_feature_maps(device):
+    """The mapped map handed to K2 / K4 may be an [:h,:w] crop of a padded channels-last map (real ScanNet frames use 59 of 60
+    feature rows): gradients must land on the cropped pixels -- same values as for a dense copy of the crop,
+    nothing outside it."""
+    from nerfdet_amd.autograd import DensityFeatures, RayViewStats
+    from nerfdet_amd import ops, rays
+    g = load_golden("volume_small_s1")        # generated with img_shape (59, 80): a real crop
+    meta = golden_meta(g)
+    n_v = g["features"].shape[0]
+    cm, h, w = 8, meta["img_shape"][0] // 4, meta["img_shape"][1] // 4
+    torch.manual_seed(0)
+    padded = torch.randn(n_v, h + 1, w + 2, cm, device=device)            # (n,H,W,C) memory with spare rows and columns
+    bias = torch.randn(cm, device=device)
+    pts, proj, rgb_proj = g["points"].to(device), g["projection"].to(device), g["rgb_projection"].to(device)
+    rgb = g["denorm_images"][:, :, :meta["img_shape"][0], :meta["img_shape"][1]].to(device)
+    outs = {}
+    for kind in ("crop", "dense"):
+        base = padded.clone().requires_grad_(True)
+        view = base.permute(0, 3, 1, 2)[:, :, :h, :w]
+        m = view if kind == "crop" else view.contiguous(memory_format=torch.channels_last)
+        b = bias.clone().requires_grad_(True)
+        glob = DensityFeatures.apply(m, b, rgb, pts, proj, rgb_proj)
+        wt = torch.randn(glob.shape, generator=torch.Generator().manual_seed(1)).to(device)
+        (glob * wt).sum().backward()
+        xyz = (torch.rand(40, 6, 3, generator=torch.Generator().manual_seed(2)) * 4 - 2).to(device)
+        cams = rays._compute_projection(meta)
+        base2 = padded.clone().requires_grad_(True)
+        view2 = base2.permute(0, 3, 1, 2)[:, :, :h, :w]
+        f = view2 if kind == "crop" else view2.contiguous(memory_format=torch.channels_last)
+        gf, _, _ = RayViewStats.apply(f, xyz, rgb, cams)
+        wt2 = torch.randn(gf.shape, generator=torch.Generator().manual_seed(3)).to(device)
+        (gf * wt2).sum().backward()
+        outs[kind] = (glob.detach(), base.grad, b.grad, gf.detach(), base2.grad)
+    for a, c in zip(outs["crop"], outs["dense"]):
+        _close(a.cpu(), c.cpu(), tol=1e-5, what="crop vs dense")
+    for gr in (outs["crop"][1], outs["crop"][4]):
+        assert float(gr[:, h:].abs().max()) == 0 and float(gr[:, :, w:].abs().max()) == 0     # nothing outside the crop
+        assert float(gr[:, :h, :w].abs().max()) > 0

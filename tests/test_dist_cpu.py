@@ -71,5 +71,33 @@ def test_shard_and_collect_single_process():
     from nerfdet_amd import dist as D
     assert D.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
     assert D.shard_indices(5, 2, 4) == [2, 1] and D.shard_indices(5, 1, 4) == [1, 0]  # n=5, world=4: per=2, pad 3 by wrapping
+    # fewer scenes than ranks: the padding wraps around the 3 scenes and never leaves the range (DistributedSampler)
+    shards = [D.shard_indices(3, r, 8) for r in range(8)]
+    assert shards == [[0], [1], [2], [0], [1], [2], [0], [1]]
+    assert D.shard_indices(0, 0, 4) == []
     assert D.collect_results([1, 2, 3], 2) == [1, 2]
     assert D.max_over_ranks(0.25) == 0.25
+
+
+@pytest.mark.timeout(180)
+def test_bench_launches_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` with no launcher in the environment spawns its two ranks itself (fresh children, the parent
+    never initialises a device), they rendezvous, and ONE JSON line comes back with n_gpus=2 and the slowest rank's time.
+    ``--dry-run`` swaps the GPU step for a sleep so that the plumbing runs on the CPU."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run"],
+                         env=env, capture_output=True, text=True, timeout=150)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["dry_run"] is True
+    assert d["ms_per_step"] >= 4.0          # rank 1 sleeps 4 ms per step, rank 0 2 ms: the job's time is the slowest rank's
+    assert abs(d["value"] - 2 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
+    # a rank that dies takes the job down with a non-zero exit code instead of leaving the others in the barrier
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "tiny"],
+                         env=dict(env, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""), capture_output=True, text=True, timeout=150)
+    assert bad.returncode != 0 and "bench.py needs a GPU" in bad.stderr

@@ -41,8 +41,14 @@ def test_bench_bookkeeping():
     assert (w["n_views"], w["img_hw"], w["n_voxels"]) == (50, (240, 320), (40, 40, 16))
     # every FPN feature row once + (C fp32 + int64 count) per voxel
     assert bench.k1_algorithmic_bytes(w) == 50 * 256 * 60 * 80 * 4 + (256 * 4 + 8) * 25600 == 272179200
-    traffic, src = bench.k1_measured_traffic("cfg2")
-    assert traffic is not None and traffic > bench.k1_algorithmic_bytes(w) and src.startswith("profiles/")
+    # 46.08 MB of images + 30.72 MB of mapped features + 70 floats per voxel
+    assert bench.k2_algorithmic_bytes(w) == 4 * (50 * 3 * 240 * 320 + 50 * 32 * 60 * 80 + 70 * 25600) == 83968000
+    traffic, src = bench.measured_traffic("cfg2")
+    assert traffic["k_backproject_aggregate"] > bench.k1_algorithmic_bytes(w) and src.startswith("profiles/")
+    # BASELINE.json configs[4] as stated: ResNet-101, 101 views 320x480, 80x80x32 voxels
+    w5 = bench.WORKLOADS["cfg5"]
+    assert (w5["n_views"], w5["img_hw"], w5["n_voxels"], w5["depth"]) == (101, (320, 480), (80, 80, 32), 101)
+    assert bench.k1_algorithmic_bytes(w5) == 101 * 256 * 80 * 120 * 4 + (256 * 4 + 8) * 204800
     batch = bench.synth_batch(bench.WORKLOADS["tiny"], 3)
     assert batch["img"].shape == (1, 6, 3, 64, 96) and len(batch["img_metas"][0]["lidar2img"]["extrinsic"]) == 6
     assert bench.HBM_PEAK_GBS == 8000.0 and bench.MFMA_BF16_PEAK_TFLOPS == 2500.0 and bench.MFMA_F32_PEAK_TFLOPS == 157.3
