@@ -105,6 +105,14 @@ def build_model(w):
     det = build_nerfdet(w["depth"], n_voxels=w["n_voxels"], voxel_size=w["voxel_size"])
     with torch.no_grad():
         det.neck.fpn_convs[0].conv.weight.mul_(1 / 30.0)
+        if w["depth"] != 50:
+            # a deeper random-init ResNet without calibrated BatchNorm statistics grows its activations with depth (x1000 at 101
+            # layers): bring FPN level 0 to the scale the ResNet-50 workload has (std ~2), measured on two small random views
+            g = torch.Generator().manual_seed(1)
+            det.eval()
+            std = float(det.neck(det.backbone(torch.randn(2, 3, 120, 160, generator=g)))[0].std())
+            det.neck.fpn_convs[0].conv.weight.mul_(2.0 / std)
+            det.neck.fpn_convs[0].conv.bias.mul_(2.0 / std)
         det.nerf_mlp.mlp.sigma_layer.output_layer.bias.fill_(2.0)
         det.bbox_head.cls_conv.weight.normal_(0, 0.3)
         det.bbox_head.cls_conv.bias.fill_(-2.0)

@@ -82,6 +82,16 @@ int ndet_density_features(const float* mapped_nhwc, int n_views, int cm, int h, 
                           const float* points, int N, const float* projection, const float* rgb_projection,
                           float* global_feat, void* stream);
 
+/* A5, packed form (the inference path's kernel): same statement, inputs and output layout as ndet_density_features --
+ * nerfdet.py:234-253 -- for cm % 4 == 0 and n_views <= 128: channel quads per lane, 64/(cm/4+1) voxels per wavefront, both
+ * projections of a (voxel, view) pair evaluated once, only the views that see the voxel are walked, and the variance uses the
+ * shifted one-pass form (equal to the reference's two-pass sum up to fp32 rounding, not bit-equal). */
+int ndet_density_features_packed(const float* mapped_nhwc, int n_views, int cm, int h, int w,
+                                 int64_t mview_pitch, int64_t mrow_pitch, const float* bias,
+                                 const float* rgb, int H, int W, int64_t rsv, int64_t rsc, int64_t rsy,
+                                 const float* points, int N, const float* projection,
+                                 const float* rgb_projection, float* global_feat, void* stream);
+
 /* A6 (gating only, unfused form). volume = (1-exp(-density)) * mean, 0 where count==0; nerfdet.py:257-261.
  * mean/out in `layout` with C channels. */
 int ndet_alpha_gate(const float* mean, const float* density, const int64_t* count, float* out,
@@ -154,6 +164,22 @@ int ndet_ray_view_stats(const float* pts, int n_points, const float* KE, int n_v
                         const float* rgb, int H, int W, int64_t rsv, int64_t rsc, int64_t rsy,
                         const float* feat_nhwc, int d, int hf, int wf, int64_t fview_pitch, int64_t frow_pitch,
                         float* global_feat, uint8_t* pixel_mask, int* view_count, void* stream);
+
+/* Source images as (n_views,H,W,4) fp32 (4th component 0) for the packed sampler below: one image pixel = one 16-byte load.
+ * rgb: element (v,c,y,x) at v*rsv + c*rsc + y*rsy + x -- the (n_v,3,H,W) ``denorm_images`` the reference permutes to
+ * (1,n_v,H,W,3) before Projector.compute (model_utils/render_ray.py:296-299).  Once per scene. */
+int ndet_pack_rgb_nhwc4(const float* rgb, int n_views, int H, int W, int64_t rsv, int64_t rsc, int64_t rsy, float* out_nhwc4,
+                        void* stream);
+
+/* A7+A8 fused, packed form (the training / render_testing hot kernel): same outputs as ndet_ray_view_stats -- Projector.compute()
+ * (model_utils/projection.py:91-151) + compute_mask_points() (render_ray.py:71-93) + the concat / pixel mask of render_ray.py:301-303 --
+ * for d % 4 == 0 and n_views <= 128.  rgb_nhwc4 from ndet_pack_rgb_nhwc4.  Each (sample, view) is projected once; views without a
+ * bilinear tap inside a map are counted, not gathered (they sample exactly 0); the variance uses the shifted one-pass form
+ * (equal to the reference's two-pass sum up to fp32 rounding, not bit-equal). */
+int ndet_ray_view_stats_packed(const float* pts, int n_points, const float* KE, int n_views, float img_h, float img_w,
+                               const float* rgb_nhwc4, int H, int W, const float* feat_nhwc, int d, int hf, int wf,
+                               int64_t fview_pitch, int64_t frow_pitch, float* global_feat, uint8_t* pixel_mask, int* view_count,
+                               void* stream);
 
 /* A7 exact API form. Replaces Projector.compute(), projection.py:91-151: rgb_feat (P, n_views, 3+d) and
  * mask (P, n_views) fp32 0/1, materialised like the reference. Same inputs as ndet_ray_view_stats. */
@@ -257,6 +283,12 @@ int ndet_density_features_bwd(const float* grad_global_feat, const float* mapped
 int ndet_ray_view_stats_bwd(const float* grad_global_feat, const float* pts, int n_points, const float* KE, int n_views,
                             float img_h, float img_w, const float* feat_nhwc, int d, int hf, int wf,
                             int64_t fview_pitch, int64_t frow_pitch, float* grad_feat_nhwc, void* stream);
+
+/* Packed form of ndet_ray_view_stats_bwd (d % 4 == 0, n_views <= 128): F.grid_sample backward (projection.py:127) through the
+ * masked statistics of render_ray.py:83-88; grad_feat_nhwc shares feat_nhwc's pitches and must be zero-initialised. */
+int ndet_ray_view_stats_packed_bwd(const float* grad_global_feat, const float* pts, int n_points, const float* KE, int n_views,
+                                   float img_h, float img_w, const float* feat_nhwc, int d, int hf, int wf, int64_t fview_pitch,
+                                   int64_t frow_pitch, float* grad_feat_nhwc, void* stream);
 
 /* d(raw) of ndet_composite (render_ray.py:196-236) from d(rgb_map) (R,3) and d(depth_map) (R) or NULL.
  * transparency: the forward's (R,S) output. */

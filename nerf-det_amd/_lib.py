@@ -28,6 +28,8 @@ SIGNATURES = {
     "ndet_backproject_aggregate": ([_P, c_int, c_int, c_int, c_int, c_int64, c_int64, _P, c_int, _P, _P, _P, c_int, _P, _P], c_int),
     "ndet_density_features": ([_P, c_int, c_int, c_int, c_int, c_int64, c_int64, _P, _P, c_int, c_int, c_int64, c_int64,
                                c_int64, _P, c_int, _P, _P, _P, _P], c_int),
+    "ndet_density_features_packed": ([_P, c_int, c_int, c_int, c_int, c_int64, c_int64, _P, _P, c_int, c_int, c_int64, c_int64,
+                                      c_int64, _P, c_int, _P, _P, _P, _P], c_int),
     "ndet_alpha_gate": ([_P, _P, _P, _P, c_int, c_int, c_int, _P], c_int),
     "ndet_sigma_to_alpha": ([_P, _P, c_int, _P], c_int),
     "ndet_posenc_concat": ([_P, _P, c_int, c_int, c_int, _P, _P], c_int),
@@ -38,6 +40,10 @@ SIGNATURES = {
     "ndet_sample_along_rays": ([_P, _P, c_int, c_int, c_float, c_float, _P, _P, _P, _P], c_int),
     "ndet_ray_view_stats": ([_P, c_int, _P, c_int, c_float, c_float, _P, c_int, c_int, c_int64, c_int64, c_int64,
                              _P, c_int, c_int, c_int, c_int64, c_int64, _P, _P, _P, _P], c_int),
+    "ndet_pack_rgb_nhwc4": ([_P, c_int, c_int, c_int, c_int64, c_int64, c_int64, _P, _P], c_int),
+    "ndet_ray_view_stats_packed": ([_P, c_int, _P, c_int, c_float, c_float, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int64, c_int64,
+                                    _P, _P, _P, _P], c_int),
+    "ndet_ray_view_stats_packed_bwd": ([_P, _P, c_int, _P, c_int, c_float, c_float, _P, c_int, c_int, c_int, c_int64, c_int64, _P, _P], c_int),
     "ndet_project_sample": ([_P, c_int, _P, c_int, c_float, c_float, _P, c_int, c_int, c_int64, c_int64, c_int64,
                              _P, c_int, c_int, c_int, c_int64, c_int64, _P, _P, _P], c_int),
     "ndet_composite": ([_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P], c_int),

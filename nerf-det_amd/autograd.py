@@ -106,8 +106,10 @@ class RayViewStats(torch.autograd.Function):
         g = g.float().reshape(pts.shape[0], -1).contiguous()
         df = torch.zeros((n_v, hf, wf, d), dtype=torch.float32, device=g.device)
         assert (f.stride(0), f.stride(2)) == (df.stride(0), df.stride(1)), "saved input and gradient buffer must share their pitches"
-        check(_lib.load().ndet_ray_view_stats_bwd(_ptr(g), _ptr(pts), pts.shape[0], _ptr(ke), n_v, ctx.hw[0], ctx.hw[1], _ptr(f), d, hf, wf,
-                                                  f.stride(0), f.stride(2), _ptr(df), _stream(g)), "ray_view_stats_bwd")
+        from . import rays
+        fn = _lib.load().ndet_ray_view_stats_packed_bwd if rays.packed_ok(n_v, d, backward=True) else _lib.load().ndet_ray_view_stats_bwd
+        check(fn(_ptr(g), _ptr(pts), pts.shape[0], _ptr(ke), n_v, ctx.hw[0], ctx.hw[1], _ptr(f), d, hf, wf, f.stride(0), f.stride(2), _ptr(df),
+                 _stream(g)), "ray_view_stats_bwd")
         return df.permute(0, 3, 1, 2), None, None, None
 
 

@@ -188,6 +188,15 @@ def backproject_aggregate(features: Tensor, points: Tensor, projection: Tensor, 
 # --------------------------------------------------------------------------------------------
 # K2: A5
 # --------------------------------------------------------------------------------------------
+def density_packed_ok(n_views: int, cm: int, mapped: Optional[Tensor] = None, bias: Optional[Tensor] = None) -> bool:
+    """Shapes the packed K2 kernel (csrc/density_kernels.hip) takes; everything else runs on the generic kernel."""
+    if cm % 4 or cm > 128 or n_views > 128 or 4 * (64 // (cm // 4 + 1)) * ((n_views + 63) // 64 * 64) * 8 > 64 * 1024:
+        return False
+    if mapped is not None and (mapped.stride(0) % 4 or mapped.stride(2) % 4 or mapped.data_ptr() % 16):
+        return False
+    return bias is None or bias.data_ptr() % 16 == 0
+
+
 def density_features(mapped: Tensor, bias: Tensor, denorm_images: Tensor, points: Tensor, projection: Tensor,
                      rgb_projection: Tensor) -> Tensor:
     """(N, 2*(3+cm)) NeRF conditioning rows for the voxel grid; replaces nerfdet.py:234-253.
@@ -206,8 +215,10 @@ def density_features(mapped: Tensor, bias: Tensor, denorm_images: Tensor, points
     points, projection, rgb_projection, bias = _f32c(points), _f32c(projection), _f32c(rgb_projection), _f32c(bias)
     out = torch.empty((n, 2 * (3 + cm)), dtype=torch.float32, device=m.device)
     # algorithmic bytes: images + mapped map read once, 2*(3+cm) floats written per voxel
+    lib = _lib.load()
+    fn = lib.ndet_density_features_packed if density_packed_ok(n_v, cm, m, bias) else lib.ndet_density_features
     trace.span("k_density_features", lambda: check(
-        _lib.load().ndet_density_features(_ptr(m), n_v, cm, h, w, m.stride(0), m.stride(2), _ptr(bias), _ptr(rgb), hh, ww, rgb.stride(0),
+        fn(_ptr(m), n_v, cm, h, w, m.stride(0), m.stride(2), _ptr(bias), _ptr(rgb), hh, ww, rgb.stride(0),
                                           rgb.stride(1), rgb.stride(2), _ptr(points), n, _ptr(projection), _ptr(rgb_projection), _ptr(out),
                                           _stream(m)), "density_features"),
         bytes=4 * (n_v * 3 * hh * ww + n_v * cm * h * w + 2 * (3 + cm) * n), kind="hbm")

@@ -65,6 +65,35 @@ def _prep_sources(train_imgs: Tensor, featmaps: Tensor):
     return rgb, f
 
 
+_PACKED_RGB = {}  # one entry: the (n_v,H,W,4) copy of the scene's source images, reused by every chunk / backward of that scene
+
+
+def packed_rgb(rgb: Tensor) -> Tensor:
+    """(n_v,3,H,W) -> dense (n_v,H,W,4) fp32, 4th component 0 (one image pixel = one 16-byte load in the packed sampler).  Cached
+    for the tensor it was made from (``render_testing`` walks one scene in hundreds of chunks)."""
+    key = (rgb.data_ptr(), rgb._version, tuple(rgb.shape), tuple(rgb.stride()), str(rgb.device))
+    hit = _PACKED_RGB.get("last")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    n_v, _, h, w = rgb.shape
+    out = torch.empty((n_v, h, w, 4), dtype=torch.float32, device=rgb.device)
+    check(_lib.load().ndet_pack_rgb_nhwc4(_ptr(rgb), n_v, h, w, rgb.stride(0), rgb.stride(1), rgb.stride(2), _ptr(out), _stream(rgb)),
+          "pack_rgb_nhwc4")
+    _PACKED_RGB["last"] = (key, out, rgb)   # keeps the source alive so that its data_ptr stays unique
+    return out
+
+
+def packed_ok(n_views: int, d: int, backward: bool = False) -> bool:
+    """Shapes the packed sampler (csrc/ray_stats_kernels.hip) takes; everything else runs on the generic kernel."""
+    if d % 4 or d > 128 or n_views > 128:
+        return False
+    lanes = d // 4 + (0 if backward else 1)
+    g, nvp = 64 // lanes, (n_views + 63) // 64 * 64
+    if backward:
+        return d <= 64 and 4 * g * nvp * 8 + 4 * g * d * 16 + 4 * g * 32 <= 64 * 1024
+    return 4 * g * nvp * 8 <= 64 * 1024
+
+
 def ray_view_stats(xyz: Tensor, train_imgs: Tensor, train_cameras: Tensor, featmaps: Tensor):
     """Fused A7+A8: sample points (R,S,3) -> ``globalfeat`` (R,S,2*(3+d)), ``pixel_mask`` (R,S) bool,
     ``view_count`` (R,S) int32.  Equals Projector.compute + compute_mask_points + cat + ``mask.sum(2) > 1``
@@ -83,12 +112,19 @@ def ray_view_stats(xyz: Tensor, train_imgs: Tensor, train_cameras: Tensor, featm
     glob = torch.empty((n, 2 * (3 + d)), dtype=torch.float32, device=xyz.device)
     pm = torch.empty((n,), dtype=torch.bool, device=xyz.device)
     vc = torch.empty((n,), dtype=torch.int32, device=xyz.device)
-    # algorithmic bytes: images + mapped map read once, 2*(3+d) floats written per sample
+    nbytes = 4 * (n_v * 3 * rgb.shape[2] * rgb.shape[3] + n_v * d * hf * wf + 2 * (3 + d) * n)
+    if packed_ok(n_v, d) and f.stride(0) % 4 == 0 and f.stride(2) % 4 == 0 and f.data_ptr() % 16 == 0:
+        rgb4 = packed_rgb(rgb)
+        trace.span("k_ray_stats_packed", lambda: check(
+            _lib.load().ndet_ray_view_stats_packed(_ptr(pts), n, _ptr(ke), n_v, h, w, _ptr(rgb4), rgb.shape[2], rgb.shape[3], _ptr(f), d, hf, wf,
+                                                   f.stride(0), f.stride(2), _ptr(glob), _ptr(pm), _ptr(vc), _stream(xyz)),
+            "ray_view_stats_packed"), bytes=nbytes, kind="hbm")
+        return glob.view(*shape, -1), pm.view(*shape), vc.view(*shape)
     trace.span("k_ray_view_stats", lambda: check(
         _lib.load().ndet_ray_view_stats(_ptr(pts), n, _ptr(ke), n_v, h, w, _ptr(rgb), rgb.shape[2], rgb.shape[3], rgb.stride(0), rgb.stride(1),
                                         rgb.stride(2), _ptr(f), d, hf, wf, f.stride(0), f.stride(2), _ptr(glob), _ptr(pm), _ptr(vc),
                                         _stream(xyz)), "ray_view_stats"),
-        bytes=4 * (n_v * 3 * rgb.shape[2] * rgb.shape[3] + n_v * d * hf * wf + 2 * (3 + d) * n), kind="hbm")
+        bytes=nbytes, kind="hbm")
     return glob.view(*shape, -1), pm.view(*shape), vc.view(*shape)
 
 

@@ -178,4 +178,4 @@ def test_ddp_two_ranks_gloo_cpu_gradients_are_the_rank_mean():
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
 def test_ddp_two_ranks_hip_autograd_functions_gradients_are_the_rank_mean(device):
-    _run("cuda", 2e-3)
+    _run("cuda", 1e-2)   # float atomics in the scatter kernels + library backward kernels: run-to-run noise of a few 1e-3 of the scale

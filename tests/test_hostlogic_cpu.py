@@ -52,3 +52,13 @@ def test_bench_bookkeeping():
     batch = bench.synth_batch(bench.WORKLOADS["tiny"], 3)
     assert batch["img"].shape == (1, 6, 3, 64, 96) and len(batch["img_metas"][0]["lidar2img"]["extrinsic"]) == 6
     assert bench.HBM_PEAK_GBS == 8000.0 and bench.MFMA_BF16_PEAK_TFLOPS == 2500.0 and bench.MFMA_F32_PEAK_TFLOPS == 157.3
+
+
+def test_hand_placed_vmcnt_waits_cover_their_dma_groups():
+    """tools/audit_vmcnt.py: every hand-placed ``s_waitcnt vmcnt(N)`` of the convolution kernels has, on every control-flow path of
+    the gfx950 disassembly, at least N vector-memory instructions between the LDS-DMA group it protects and itself."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_vmcnt.py")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert "0 short windows" in out.stdout and "k_conv_split_ws" in out.stdout and "k_conv_split_halo" in out.stdout

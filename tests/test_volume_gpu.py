@@ -284,3 +284,37 @@ def test_sigma_mlp_on_matrix_cores_vs_oracle(device):
         got = mlp.alpha_from_points(pts.to(device), glob.to(device))
     assert (ref > 0).float().mean() > 0.2
     torch.testing.assert_close(got.cpu(), ref.reshape(-1), rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("n_v,cm,hw,grid,vs", [(50, 32, (240, 320), (40, 40, 16), (0.16, 0.16, 0.2)), (101, 32, (120, 160), (20, 20, 9), (0.32, 0.32, 0.36)),
+                                               (7, 8, (60, 80), (10, 6, 5), (0.6, 0.9, 0.6)), (3, 48, (48, 64), (9, 7, 3), (0.7, 0.7, 0.9))])
+def test_packed_density_features_equal_generic_kernel(device, n_v, cm, hw, grid, vs):
+    """csrc/density_kernels.hip (channel quads, 64/(cm/4+1) voxels per wave, seen views only, shifted one-pass variance) against the
+    generic two-pass kernel on the same inputs, incl. the cnt == 0 conventions; cfg2 size, two view rounds, ragged tails."""
+    from ctypes import c_void_p
+    from nerfdet_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed(n_v + cm)
+    meta = O.ring_scene_meta(n_v, hw)
+    mapped = torch.randn(n_v, cm, hw[0] // 4, hw[1] // 4, generator=g).to(device).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(cm, generator=g).to(device)
+    rgb = torch.rand(n_v, 3, *hw, generator=g).to(device)
+    pts = O.get_points(grid, vs, meta["lidar2img"]["origin"]).to(device)
+    proj, rgb_proj = O.compute_projection(meta, 4).to(device), O.compute_projection(meta, 1).to(device)
+    assert ops.density_packed_ok(n_v, cm, mapped, bias)
+    got = ops.density_features(mapped, bias, rgb, pts, proj, rgb_proj)
+    saved = ops.density_packed_ok
+    ops.density_packed_ok = lambda *a, **k: False
+    try:
+        ref = ops.density_features(mapped, bias, rgb, pts, proj, rgb_proj)
+    finally:
+        ops.density_packed_ok = saved
+    _, cnt = ops.backproject_aggregate(mapped, pts, proj)
+    seen = cnt.reshape(-1) > 0
+    assert 0.05 < float(seen.float().mean()) < 1.0
+    torch.testing.assert_close(got[seen], ref[seen], rtol=0, atol=ATOL)
+    # unseen voxels: cov exactly 0; the "mean" is the reference's n_v * fill / 1e-8 (huge): same to fp32 relative rounding
+    un = ~seen
+    if un.any():
+        assert float(got[un][:, 1::2].abs().max()) == 0 and float(ref[un][:, 1::2].abs().max()) == 0
+        torch.testing.assert_close(got[un][:, 0::2], ref[un][:, 0::2], rtol=1e-5, atol=1e-3)
