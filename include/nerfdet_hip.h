@@ -227,6 +227,12 @@ int ndet_conv_ndhwc(const float* in, const float* w_packed, float* out, int D, i
  * weights of ndet_conv_ndhwc_split (the conv weights of necks/imvoxelnet.py:36-67, dense_heads/imvoxel_head_v2.py:45-49). */
 int ndet_split_weights_bf16x3(const float* w_packed, int taps, int Cout, int Cin, uint16_t* planes, void* stream);
 
+/* The same planes straight from a torch-layout weight (Cout, Cin, taps) -- training re-packs every step.  adjoint = 0: the layer's
+ * own weight, planes (taps, Cin/32, 3, Cout, 32).  adjoint = 1: the weight of the layer's data gradient (autograd of the
+ * convolutions of mmdet3d/models/necks/imvoxelnet.py:22-67,233-260), W'[t][ci][co] = W[co][ci][taps-1-t], planes
+ * (taps, ceil32(Cout)/32, 3, Cin, 32) with the padded input channels zero. */
+int ndet_split_weights_bf16x3_torch(const float* w_torch, int taps, int Cout, int Cin, int adjoint, uint16_t* planes, void* stream);
+
 /* Same contract as ndet_conv_ndhwc / the transposed form of ndet_conv3d_ndhwc, computed on the bf16 matrix cores:
  * weights as tiled bf16 planes (taps, Cin/32, 3, Cout, 32) from ndet_split_weights_bf16x3, activations split on the fly; the six
  * products of order <= 2 are accumulated in fp32 (error at the level of an fp32 FMA chain).  transposed = 1: k2 s2
@@ -262,6 +268,14 @@ int ndet_normalize_views(const uint8_t* frames_bgr, const int* ids, int n_sel, i
 int ndet_target_rays(const uint8_t* frames_bgr, const int* target_ids, int n_targets, int H, int W, int margin,
                      const float* intrinsic_rows, const float* camrotc2w, const float* cam_lightpos, const double* mean_rgb,
                      const double* std_rgb, float* raydirs, float* lightpos, float* gt_images, void* stream);
+
+/* Weight-gradient staging for the training-time convolutions (autograd of nn.Conv3d / nn.Conv2d in
+ * mmdet3d/models/necks/imvoxelnet.py:22-67,233-260 and of the third-party ResNet/FPN layers): channels-last x (D,H,W,C) -> rows
+ * out[t - t0][c][j] = xpad[c][j + off(t) - margin] over the zero-padded flattened grid (pads pd,ph,pw), taps t0 .. t0+n_taps-1 of a
+ * (kd,kh,kw) stride-1 kernel; every element of out (n_taps, C, lrow) is written (zeros in halo and margins).  With these rows the
+ * weight gradient is one GEMM over j on ndet_conv_ndhwc_split (nerfdet_amd/conv_train.py). */
+int ndet_wgrad_rows(const float* x_ndhwc, int D, int H, int W, int C, int kd, int kh, int kw, int pd, int ph, int pw, int t0,
+                    int n_taps, int margin, int lrow, float* out, void* stream);
 
 /* ---- backward passes (training).  The reference obtains these from autograd over its materialised tensors; each
  * entry point names the forward statement it differentiates.  Scatter targets must be zero-initialised by the caller;

@@ -52,12 +52,14 @@ SIGNATURES = {
     "ndet_ray_view_stats_bwd": ([_P, _P, c_int, _P, c_int, c_float, c_float, _P, c_int, c_int, c_int, c_int64, c_int64, _P, _P], c_int),
     "ndet_composite_bwd": ([_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P], c_int),
     "ndet_split_weights_bf16x3": ([_P, c_int, c_int, c_int, _P, _P], c_int),
+    "ndet_split_weights_bf16x3_torch": ([_P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_conv_ndhwc_split": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_level_valid": ([_P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_select_candidates": ([c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P], c_int),
     "ndet_gather_detections": ([_P, c_int, _P, _P, _P, _P, _P, _P, _P], c_int),
     "ndet_normalize_views": ([_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P], c_int),
     "ndet_target_rays": ([_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
+    "ndet_wgrad_rows": ([_P] + [c_int] * 14 + [_P, _P], c_int),
     "ndet_bn_relu_maxpool_nhwc": ([_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_conv3d_workspace_bytes": ([c_int] * 8, c_int64),
     "ndet_conv_ndhwc": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),

@@ -12,6 +12,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .conv3d import bn_relu_maxpool_nhwc, conv2d_nhwc, packed
+from .conv_train import conv_forward
 from .registry import BACKBONES, NECKS
 
 
@@ -35,10 +36,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        # training on the GPU: the stride-1 convolutions run on the MFMA kernels, forward and backward (nerfdet_amd/conv_train.py)
         idt = x if self.downsample is None else self.downsample(x)
-        out = F.relu(self.bn1(self.conv1(x)), inplace=True)
-        out = F.relu(self.bn2(self.conv2(out)), inplace=True)
-        out = self.bn3(self.conv3(out))
+        out = F.relu(self.bn1(conv_forward(self.conv1, x)), inplace=True)
+        out = F.relu(self.bn2(conv_forward(self.conv2, out)), inplace=True)
+        out = self.bn3(conv_forward(self.conv3, out))
         return F.relu(out + idt, inplace=True)
 
     def forward_nhwc(self, x):
@@ -180,7 +182,7 @@ class _Conv(nn.Module):
         self.conv = nn.Conv2d(cin, cout, k, padding=padding)
 
     def forward(self, x):
-        return self.conv(x)
+        return conv_forward(self.conv, x)
 
 
 @NECKS.register_module()

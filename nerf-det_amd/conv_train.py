@@ -1,0 +1,183 @@
+"""Training-time convolutions on the hand-written MFMA kernels (SURVEY.md 8a rows A13/A14 in ``forward_train``).
+
+Forward, data gradient and weight gradient of the stride-1 same-padded convolutions -- nine of the thirteen convolutions of
+``FastIndoorImVoxelNeck`` (mmdet3d/models/necks/imvoxelnet.py:22-67,233-260; 446 of its 490 GFLOP) and the stride-1 layers of
+the trainable ResNet stages / FPN -- all run on ``ndet_conv_ndhwc_split`` (csrc/conv_split_kernels.hip), no new device code:
+
+  forward   y = conv(x, W)                                         the inference kernel, no epilogue
+  dgrad     dx = conv(dy, W'),  W'[ci, co, t] = W[co, ci, flip(t)]  the same kernel on the transposed, tap-flipped weight
+  wgrad     dW[t][co][ci] = sum_v dy[v][co] x[v + off(t)][ci]       ONE launch of the same kernel as a plain GEMM:
+            both tensors are laid out channel-major over the zero-padded, flattened voxel grid -- then a tap is a constant
+            shift of the contraction index -- the 27 (9, 1) shifted copies of x are stacked as GEMM rows (T*Cin, L), dy (Cout, L)
+            plays the "weight" operand (split into its bf16 planes once), and the contraction runs over the L padded voxels.
+            Rows read past their end only where dy is zero (halo and margins), so the wrap-around is harmless.
+
+Strided convolutions, transposed convolutions and the tiny head convolutions stay on the vendor library.  BatchNorm in training
+mode (batch statistics, BasicBlock3dV2) is left to ATen on the same channels-last memory; nothing is copied between layouts."""
+from __future__ import annotations
+
+from typing import Sequence, Tuple
+
+import torch
+from torch import nn
+
+from . import conv3d as C
+
+Tensor = torch.Tensor
+
+
+def _raw_pack(w_taps_co_ci: Tensor, kernel: Sequence[int]) -> dict:
+    """Pack dict of nerfdet_amd.conv3d for a bare weight already in (taps, Cout, Cin) order: no BatchNorm, no bias, stride 1."""
+    k = tuple(int(v) for v in kernel)
+    ndim = len(k)
+    return dict(w=w_taps_co_ci.contiguous().float(), scale=None, shift=None, cout=int(w_taps_co_ci.shape[1]), cin=int(w_taps_co_ci.shape[2]),
+                ksize=k[0], stride=1, transposed=False, kernel=k, strides=(1,) * ndim, pads=tuple(v // 2 for v in k), ndim=ndim)
+
+
+def _train_pack(w: Tensor, kernel, adjoint: bool) -> dict:
+    """Pack dict for the layer (or, ``adjoint``, for its data gradient) straight from the torch-layout weight: with the bf16x3
+    kernels one launch writes the three bf16 planes (ndet_split_weights_bf16x3_torch); the fp32-MFMA family goes through the
+    generic packer."""
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    taps = 1
+    for v in kernel:
+        taps *= int(v)
+    if C.ARITHMETIC != "bf16x3":
+        if not adjoint:
+            return _raw_pack(C.pack_weight(w), kernel)
+        flip = w.flip(tuple(range(2, w.dim()))).transpose(0, 1)
+        if cout % 32:
+            flip = torch.nn.functional.pad(flip, (0, 0) * (w.dim() - 2) + (0, 32 - cout % 32))
+        return _raw_pack(C.pack_weight(flip), kernel)
+    from ctypes import c_void_p
+    from . import _lib
+    no, ki = (cin, (cout + 31) // 32 * 32) if adjoint else (cout, cin)
+    planes = torch.empty((taps, ki // 32, 3, no, 32), dtype=torch.int16, device=w.device)
+    wc = w.contiguous()
+    _lib.check(_lib.load().ndet_split_weights_bf16x3_torch(c_void_p(wc.data_ptr()), taps, cout, cin, int(adjoint), c_void_p(planes.data_ptr()),
+                                                           c_void_p(torch.cuda.current_stream(w.device).cuda_stream)), "split_weights_torch")
+    k = tuple(int(v) for v in kernel)
+    return dict(w=wc, w_split=planes, scale=None, shift=None, cout=no, cin=ki, ksize=k[0], stride=1, transposed=False, kernel=k,
+                strides=(1,) * len(k), pads=tuple(v // 2 for v in k), ndim=len(k))
+
+
+def _conv(x: Tensor, pk: dict) -> Tensor:
+    return C.conv3d_ndhwc(x, pk) if pk["ndim"] == 3 else C.conv2d_nhwc(x, pk)
+
+
+def eligible(conv: nn.Module, x: Tensor) -> bool:
+    """Stride-1, odd, same-padded, un-dilated, un-grouped convolution whose input channel count the MFMA kernel steps through (a
+    multiple of 32), on a float32 GPU tensor."""
+    if not isinstance(conv, (nn.Conv3d, nn.Conv2d)) or not x.is_cuda or x.dtype != torch.float32:
+        return False
+    k = conv.kernel_size
+    if isinstance(conv, nn.Conv3d) and len(set(k)) != 1:
+        return False
+    return (all(s == 1 for s in conv.stride) and all(d == 1 for d in conv.dilation) and conv.groups == 1
+            and all(v % 2 == 1 and p == v // 2 for v, p in zip(k, conv.padding)) and conv.padding_mode == "zeros"
+            and conv.in_channels % 32 == 0)
+
+
+def _rows(x: Tensor, k3, pads, t0: int, n_taps: int, margin: int, lrow: int) -> Tensor:
+    """csrc/pipeline_kernels.hip::k_wgrad_rows: (D,H,W,C) -> (n_taps, C, lrow) shifted channel-major rows over the padded grid."""
+    from ctypes import c_void_p
+    from . import _lib
+    d, h, w, c = x.shape
+    out = torch.empty((n_taps, c, lrow), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().ndet_wgrad_rows(c_void_p(x.data_ptr()), d, h, w, c, k3[0], k3[1], k3[2], pads[0], pads[1], pads[2], t0, n_taps, margin,
+                                           lrow, c_void_p(out.data_ptr()), c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "wgrad_rows")
+    return out
+
+
+def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int]) -> Tensor:
+    """dW of a stride-1 same-padded convolution.  x (D,H,W,Cin), g (D,H,W,Cout) contiguous fp32 channels-last (2D: D = batch, kernel
+    (kh,kw)) -> (Cout, Cin, *kernel) in torch's layout."""
+    k3 = (1,) + tuple(kernel) if len(kernel) == 2 else tuple(kernel)
+    d, h, w, cin = x.shape
+    cout = g.shape[3]
+    pads = tuple(v // 2 for v in k3)
+    hp, wp = h + 2 * pads[1], w + 2 * pads[2]
+    lp = (d + 2 * pads[0]) * hp * wp
+    margin = pads[0] * hp * wp + pads[1] * wp + pads[2]     # largest |tap shift| of the flattened index
+    lrow = ((lp + 2 * margin + 31) // 32) * 32              # the kernel steps the contraction by 32
+    taps = k3[0] * k3[1] * k3[2]
+    # dy as the GEMM's "weight" operand (Cout rows over the padded grid, zeros in halo and margins), split into bf16 planes once
+    grows = _rows(g, (1, 1, 1), pads, 0, 1, margin, lrow)
+    pk = dict(w=grows, scale=None, shift=None, cout=cout, cin=lrow, ksize=1, stride=1, transposed=False, kernel=(1, 1), strides=(1, 1),
+              pads=(0, 0), ndim=2)
+    per = max(1, min(taps, (1 << 30) // (cin * lrow * 4)))  # the kernel addresses its operand with 32-bit byte offsets: <= 1 GiB per launch
+    parts = []
+    for t0 in range(0, taps, per):
+        a_all = _rows(x, k3, pads, t0, min(per, taps - t0), margin, lrow)      # rows (t, ci): x shifted by tap t
+        parts.append(C.linear_rows(a_all.view(-1, lrow), pk))                  # (taps*Cin, Cout): the sum over the padded voxels
+    dw = parts[0] if len(parts) == 1 else torch.cat(parts)
+    return dw.view(taps, cin, cout).permute(2, 1, 0).reshape(cout, cin, *kernel)
+
+
+class ConvS1(torch.autograd.Function):
+    """y = conv(x, weight) for channels-last x (D,H,W,Cin) / (N,H,W,Cin) and a torch-layout weight; see the module docstring."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        kernel = tuple(weight.shape[2:])
+        ctx.kernel = kernel
+        w = weight.detach()
+        ctx.save_for_backward(x.detach(), w)
+        return _conv(x.detach().contiguous(), _train_pack(w, kernel, False))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous().float()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # the adjoint convolution: W'[ci, co, t] = W[co, ci, flip(t)]; the kernel steps its input channels by 32, so dy (and W')
+            # are zero-padded when Cout is not a multiple
+            gd = g if g.shape[-1] % 32 == 0 else torch.nn.functional.pad(g, (0, 32 - g.shape[-1] % 32))
+            dx = _conv(gd, _train_pack(w, ctx.kernel, True))
+        if ctx.needs_input_grad[1]:
+            dw = weight_grad(x, g, ctx.kernel)
+        return dx, dw
+
+
+def conv_forward(conv: nn.Module, x: Tensor) -> Tensor:
+    """``conv(x)`` for a logical (B,C,...) tensor: eligible layers run on the MFMA kernels under autograd (channels-last memory in,
+    channels-last memory out, logical shape unchanged); everything else goes to the module itself."""
+    if not (torch.is_grad_enabled() and eligible(conv, x)):
+        return conv(x)
+    three_d = isinstance(conv, nn.Conv3d)
+    outs = []
+    if three_d:
+        for b in range(x.shape[0]):                                           # one scene at a time: the kernel's depth axis is X
+            xb = x[b].permute(1, 2, 3, 0)
+            y = ConvS1.apply(xb if xb.is_contiguous() else xb.contiguous(), conv.weight)
+            outs.append(y.permute(3, 0, 1, 2))
+        y = outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
+    else:
+        xb = x.permute(0, 2, 3, 1)
+        y = ConvS1.apply(xb if xb.is_contiguous() else xb.contiguous(), conv.weight).permute(0, 3, 1, 2)
+    if conv.bias is not None:
+        y = y + conv.bias.view(1, -1, *([1] * (y.dim() - 2)))
+    return y
+
+
+def conv_forward_shared(convs: Sequence[nn.Module], x: Tensor):
+    """Several convolutions reading the same input (the head's centerness / regression / class layers,
+    mmdet3d/models/dense_heads/imvoxel_head_v2.py:444-449) as ONE convolution over their concatenated output channels -- one forward,
+    one data gradient and one weight gradient launch instead of three each.  Returns the per-layer outputs (biases added)."""
+    if not (torch.is_grad_enabled() and all(eligible(c, x) for c in convs) and len({tuple(c.kernel_size) for c in convs}) == 1):
+        return [c(x) for c in convs]
+    w = torch.cat([c.weight for c in convs], dim=0)
+    outs = []
+    for b in range(x.shape[0]):
+        xb = x[b].permute(1, 2, 3, 0)
+        outs.append(ConvS1.apply(xb if xb.is_contiguous() else xb.contiguous(), w).permute(3, 0, 1, 2))
+    y = outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
+    res, o = [], 0
+    for c in convs:
+        part = y[:, o:o + c.out_channels]
+        if c.bias is not None:
+            part = part + c.bias.view(1, -1, 1, 1, 1)
+        res.append(part)
+        o += c.out_channels
+    return res

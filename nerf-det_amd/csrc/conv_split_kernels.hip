@@ -897,6 +897,46 @@ extern "C" int ndet_split_weights_bf16x3(const float* w_packed, int taps, int Co
     return NDET_OK;
 }
 
+// The same planes straight from a torch-layout weight (Cout, Cin, taps): `adjoint` = 0 packs the layer's own weight, 1 the weight of
+// its data gradient, W'[t][ci][co] = W[co][ci][taps - 1 - t] (tap-flipped, transposed; the new input-channel count Cout is zero-padded
+// to a multiple of 32).  Training re-packs every step (the optimizer moves the weights): one launch instead of permute + copy + split.
+__global__ __launch_bounds__(256) void k_split_weights_torch(const float* __restrict__ w, int taps, int Cout, int Cin, int adjoint, int No, int Ki,
+                                                             uint16_t* __restrict__ out) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;   // element pair along the packed input-channel axis
+    const int64_t n = (int64_t)taps * No * Ki;
+    if (i >= n) return;
+    const int ki = (int)(i % Ki), no = (int)((i / Ki) % No), tap = (int)(i / ((int64_t)Ki * No));
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int k = ki + e;
+        if (!adjoint) v[e] = w[((int64_t)no * Cin + k) * taps + tap];
+        else v[e] = k < Cout ? w[((int64_t)k * Cin + no) * taps + (taps - 1 - tap)] : 0.0f;
+    }
+    const uint32_t o0 = spl_pack(v[0], v[1]);
+    const float ra = v[0] - spl_lo(o0), rb = v[1] - spl_hi(o0);
+    const uint32_t o1 = spl_pack(ra, rb);
+    const uint32_t o2 = spl_pack(ra - spl_lo(o1), rb - spl_hi(o1));
+    const uint32_t o[3] = {o0, o1, o2};
+    const int steps = Ki / CBK;
+    uint16_t* dst = out + (((int64_t)tap * steps + ki / CBK) * 3 * No + no) * CBK + (ki % CBK);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint32_t*>(dst + (int64_t)pl * No * CBK) = o[pl];
+}
+
+extern "C" int ndet_split_weights_bf16x3_torch(const float* w_torch, int taps, int Cout, int Cin, int adjoint, uint16_t* planes, void* stream) {
+    const char* fn = "ndet_split_weights_bf16x3_torch";
+    NDET_REQUIRE(w_torch && planes, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(taps > 0 && Cout > 0 && Cin > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
+    const int No = adjoint ? Cin : Cout, Ki = adjoint ? ((Cout + CBK - 1) / CBK) * CBK : Cin;
+    NDET_REQUIRE(Ki % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
+    const int64_t work = (int64_t)taps * No * Ki / 2;
+    hipLaunchKernelGGL(k_split_weights_torch, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_torch, taps, Cout, Cin,
+                       adjoint ? 1 : 0, No, Ki, planes);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
+
 extern "C" int ndet_conv_ndhwc_split(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
                                      const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
                                      const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,

@@ -104,3 +104,62 @@ extern "C" int ndet_target_rays(const uint8_t* frames_bgr, const int* target_ids
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight-gradient staging (nerfdet_amd/conv_train.py): channels-last activations (D,H,W,C) -> channel-major rows over the
+// zero-padded, flattened grid, one copy per tap shifted by the tap's offset:
+//     out[t][c][j] = xpad[c][j + off(t) - margin]      (0 outside the grid's interior)
+// so that dW[t] = dY_rows . out[t]^T is a plain GEMM over j (autograd of nn.Conv3d / nn.Conv2d in
+// mmdet3d/models/necks/imvoxelnet.py:22-67,233-260).  Every destination element is written exactly once (halo and margins as
+// zeros): no separate clear.  64 positions x 64 channels per workgroup through an LDS transpose: reads coalesced along C, writes
+// coalesced along j.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wgrad_rows(const float* __restrict__ x, int D, int H, int W, int C, int kd, int kh, int kw, int pd,
+                                                    int ph, int pw, int t0, int margin, int lrow, float* __restrict__ out) {
+    __shared__ float tile[64][65];
+    __shared__ int src[64];                                  // source voxel of each of the 64 positions, -1 = halo / margin
+    const int j0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int t = t0 + blockIdx.z;
+    const int Hp = H + 2 * ph, Wp = W + 2 * pw;
+    const int a = t / (kh * kw), b = (t / kw) % kh, c = t % kw;
+    const int off = (a - kd / 2) * Hp * Wp + (b - kh / 2) * Wp + (c - kw / 2);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (threadIdx.x < 64) {                                  // one index decode per position (three integer divisions), not per element
+        const int vp = j0 + tx + off - margin;               // index in the padded grid
+        int s_ = -1;
+        if (vp >= 0) {
+            const int w_ = vp % Wp - pw, h_ = (vp / Wp) % Hp - ph, d_ = vp / (Wp * Hp) - pd;
+            if (w_ >= 0 && w_ < W && h_ >= 0 && h_ < H && d_ >= 0 && d_ < D) s_ = (d_ * H + h_) * W + w_;
+        }
+        src[tx] = s_;
+    }
+    __syncthreads();
+    const bool cok = c0 + tx < C;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int vj = ty + 4 * i;
+        const int s_ = src[vj];
+        tile[vj][tx] = (s_ >= 0 && cok) ? x[(int64_t)s_ * C + c0 + tx] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int ci = ty + 4 * i;
+        if (c0 + ci < C && j0 + tx < lrow) out[((int64_t)blockIdx.z * C + c0 + ci) * lrow + j0 + tx] = tile[tx][ci];
+    }
+}
+
+extern "C" int ndet_wgrad_rows(const float* x_ndhwc, int D, int H, int W, int C, int kd, int kh, int kw, int pd, int ph, int pw, int t0,
+                               int n_taps, int margin, int lrow, float* out, void* stream) {
+    const char* fn = "ndet_wgrad_rows";
+    NDET_REQUIRE(x_ndhwc && out, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(D > 0 && H > 0 && W > 0 && C > 0 && kd > 0 && kh > 0 && kw > 0 && n_taps > 0 && t0 >= 0 && t0 + n_taps <= kd * kh * kw && lrow > 0,
+                 NDET_E_INVALID, "%s: bad sizes", fn);
+    NDET_REQUIRE((int64_t)(D + 2 * pd) * (H + 2 * ph) * (W + 2 * pw) + 2 * (int64_t)margin <= lrow && margin >= 0, NDET_E_INVALID,
+                 "%s: row shorter than the padded grid plus its margins", fn);
+    NDET_REQUIRE((C + 63) / 64 <= 65535 && n_taps <= 65535, NDET_E_UNSUPPORTED, "%s: grid too large", fn);
+    hipLaunchKernelGGL(k_wgrad_rows, dim3((lrow + 63) / 64, (C + 63) / 64, n_taps), dim3(256), 0, (hipStream_t)stream, x_ndhwc, D, H, W, C, kd, kh,
+                       kw, pd, ph, pw, t0, margin, lrow, out);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}

@@ -124,9 +124,9 @@ class nerfdet(BaseDetector):
         for b, img_meta in enumerate(img_metas):
             feat = x[b * n_v:(b + 1) * n_v]
             dn = denorm.reshape([-1] + list(denorm.shape)[2:])
-            # inference: channels-last volume straight into the MFMA conv neck; training: NCDHW for the library convs
+            # channels-last volume straight into the MFMA convolutions of the 3D neck (inference and training alike)
             out = extract_volume(feat, dn, img_meta, self.n_voxels, self.voxel_size, self.mapping, self.nerf_mlp,
-                                 stride=stride, channels_last_out=not torch.is_grad_enabled(),
+                                 stride=stride, channels_last_out=True,
                                  geometry=None if geoms is None else geoms[b])
             if mode == "train" or self.render_testing:
                 from .rays import render_rays

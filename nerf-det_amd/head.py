@@ -72,6 +72,10 @@ class ScanNetImVoxelHeadV2(nn.Module):
     def forward_single(self, x, scale):
         if x.is_cuda and not self.training and not torch.is_grad_enabled() and x.shape[1] % 32 == 0:
             return self.forward_single_hip(x, scale)
+        if x.is_cuda and torch.is_grad_enabled():   # training: the three layers as one convolution on the MFMA kernels (conv_train.py)
+            from .conv_train import conv_forward_shared
+            ctr, reg, cls = conv_forward_shared([self.centerness_conv, self.reg_conv, self.cls_conv], x)
+            return ctr, torch.exp(scale(reg)), cls
         return self.centerness_conv(x), torch.exp(scale(self.reg_conv(x))), self.cls_conv(x)
 
     def forward_single_hip(self, x, scale):

@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from .conv3d import conv3d_ndhwc, packed, to_ndhwc
+from .conv_train import conv_forward
 from .registry import NECKS
 
 
@@ -27,8 +28,10 @@ class BasicBlock3dV2(nn.Module):
                                             nn.BatchNorm3d(out_channels))
 
     def forward(self, x):
-        out = self.relu(self.norm1(self.conv1(x)))
-        out = self.norm2(self.conv2(out))
+        """Library form (training: BatchNorm on batch statistics, autograd).  On the GPU the stride-1 convolutions still run on the
+        MFMA kernels, forward and backward (nerfdet_amd/conv_train.py)."""
+        out = self.relu(self.norm1(conv_forward(self.conv1, x)))
+        out = self.norm2(conv_forward(self.conv2, out))
         idt = self.downsample(x) if self.stride != 1 else x
         return self.relu(out + idt)
 
@@ -41,6 +44,13 @@ class BasicBlock3dV2(nn.Module):
 
 def _conv_bn_relu(cin, cout):
     return nn.Sequential(nn.Conv3d(cin, cout, 3, 1, 1, bias=False), nn.BatchNorm3d(cout), nn.ReLU(inplace=True))
+
+
+def _run(seq: nn.Sequential, x):
+    """``seq(x)`` with its stride-1 convolutions routed through :func:`conv_forward`."""
+    for m in seq:
+        x = conv_forward(m, x) if isinstance(m, nn.Conv3d) else m(x)
+    return x
 
 
 @NECKS.register_module()
@@ -102,6 +112,6 @@ class FastIndoorImVoxelNeck(nn.Module):
         outs = []
         for i in range(self.n_scales - 1, -1, -1):
             if i < self.n_scales - 1:
-                x = downs[i] + getattr(self, f"up_block_{i + 1}")(x)
-            outs.append(getattr(self, f"out_block_{i}")(x))
+                x = downs[i] + _run(getattr(self, f"up_block_{i + 1}"), x)
+            outs.append(_run(getattr(self, f"out_block_{i}"), x))
         return outs[::-1]

@@ -1,0 +1,106 @@
+"""Training-time convolutions on the MFMA kernels (nerfdet_amd/conv_train.py): forward, data gradient (the same kernel on the
+tap-flipped transposed weight) and weight gradient (one GEMM over the zero-padded flattened grid) against PyTorch-CPU fp32
+autograd of ``F.conv3d`` / ``F.conv2d`` -- the arithmetic mmdet3d/models/necks/imvoxelnet.py:22-67,233-260 runs in training."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+
+
+@pytest.mark.parametrize("dims,cin,cout,k", [((9, 7, 5), 64, 96, 3), ((6, 6, 4), 32, 32, 1), ((12, 10, 6), 128, 64, 3), ((8, 8, 4), 128, 25, 3),
+                                            ((3, 11, 13), 64, 32, (3, 3)), ((2, 8, 6), 96, 64, (1, 1)), ((5, 9, 9), 32, 64, (3, 3))])
+def test_conv_s1_forward_dgrad_wgrad_vs_torch_cpu(device, dims, cin, cout, k):
+    from nerfdet_amd.conv_train import ConvS1
+    torch.manual_seed(sum(dims) + cin)
+    two_d = isinstance(k, tuple)
+    ks = k if two_d else (k,) * 3
+    x = torch.randn(*dims, cin)                                    # channels-last: (D,H,W,C) or (N,H,W,C)
+    w = torch.randn(cout, cin, *ks) / (cin * max(1, ks[0] * ks[-1])) ** 0.5
+    gy = torch.randn(*dims, cout)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    if two_d:
+        ref = F.conv2d(xr.permute(0, 3, 1, 2), wr, padding=tuple(v // 2 for v in ks)).permute(0, 2, 3, 1)
+    else:
+        ref = F.conv3d(xr.permute(3, 0, 1, 2).unsqueeze(0), wr, padding=k // 2)[0].permute(1, 2, 3, 0)
+    (ref * gy).sum().backward()
+    xg, wg = x.to(device).requires_grad_(True), w.to(device).requires_grad_(True)
+    out = ConvS1.apply(xg, wg)
+    (out * gy.to(device)).sum().backward()
+    assert _rel(out.detach().cpu(), ref.detach()) <= 2e-5
+    assert _rel(xg.grad.cpu(), xr.grad) <= 2e-5
+    assert _rel(wg.grad.cpu(), wr.grad) <= 5e-5      # a sum over every voxel, in another order
+
+
+def test_neck_training_step_matches_library_path(device):
+    """``FastIndoorImVoxelNeck`` in training mode (BatchNorm on batch statistics): the routed path (stride-1 convolutions on the MFMA
+    kernels, forward and backward; the rest on the library) against an fp64 CPU evaluation of the same module -- outputs,
+    input gradient, parameter gradients and running statistics at least as close as the all-library GPU path gets (BatchNorm over
+    the 24 voxels of the coarsest level amplifies rounding, so the bar is relative to what the library achieves)."""
+    import copy
+    from nerfdet_amd import conv_train
+    from nerfdet_amd.neck3d import FastIndoorImVoxelNeck
+    torch.manual_seed(0)
+    neck = FastIndoorImVoxelNeck(64, [1, 1, 1], 32).train()
+    x = torch.randn(1, 64, 16, 12, 8)
+    wts = [torch.randn(1, 32, 16 // 2 ** i, 12 // 2 ** i, 8 // 2 ** i) for i in range(3)]
+
+    def run(mod, inp, w):
+        inp = inp.clone().requires_grad_(True)
+        outs = mod(inp)
+        sum((o * ww).sum() for o, ww in zip(outs, w)).backward()
+        return [o.detach().double().cpu() for o in outs], inp.grad.double().cpu(), {n: p.grad.double().cpu() for n, p in mod.named_parameters()}, \
+            {n: b.double().cpu() for n, b in mod.named_buffers() if b.dtype.is_floating_point}
+    exact = run(copy.deepcopy(neck).double(), x.double(), [w.double() for w in wts])
+    xg = x.to(device).contiguous(memory_format=torch.channels_last_3d)
+    ours = run(copy.deepcopy(neck).to(device), xg, [w.to(device) for w in wts])
+    saved = conv_train.eligible
+    conv_train.eligible = lambda *a, **k: False       # library everywhere
+    try:
+        lib = run(copy.deepcopy(neck).to(device), xg, [w.to(device) for w in wts])
+    finally:
+        conv_train.eligible = saved
+
+    def worst(got):
+        e = [max(_rel(a, b) for a, b in zip(got[0], exact[0])), _rel(got[1], exact[1])]
+        e.append(max(_rel(got[2][n], exact[2][n]) for n in exact[2]))
+        e.append(max(_rel(got[3][n], exact[3][n]) for n in exact[3]))
+        return e
+    e_ours, e_lib = worst(ours), worst(lib)
+    print("routed path vs fp64:", e_ours, " library path vs fp64:", e_lib)
+    for a, b, what in zip(e_ours, e_lib, ("outputs", "input gradient", "parameter gradients", "running statistics")):
+        assert a <= max(2.0 * b, 1e-4), f"{what}: {a:.2e} (library path: {b:.2e})"
+
+
+def test_head_training_forward_shares_one_convolution(device):
+    """The head's three layers as one convolution over 1 + 6 + 18 output channels (training): outputs and gradients against an fp64
+    CPU evaluation of the three separate layers (imvoxel_head_v2.py:444-449)."""
+    import copy
+    from nerfdet_amd.config import ConfigDict
+    from nerfdet_amd.head import ScanNetImVoxelHeadV2
+    torch.manual_seed(1)
+    head = ScanNetImVoxelHeadV2(n_classes=18, n_channels=128, n_reg_outs=6, n_scales=3, limit=27, centerness_topk=18,
+                                test_cfg=ConfigDict(nms_pre=1000, iou_thr=0.25, score_thr=0.01)).train()
+    with torch.no_grad():
+        for m in (head.centerness_conv, head.reg_conv, head.cls_conv):
+            m.weight.normal_(0, 0.02)
+    x = torch.randn(1, 128, 10, 8, 6)
+    wts = [torch.randn(1, c, 10, 8, 6) for c in (1, 6, 18)]
+
+    def run(h, inp, w):
+        inp = inp.clone().requires_grad_(True)
+        outs = h.forward_single(inp, h.scales[1])
+        sum((o * ww).sum() for o, ww in zip(outs, w)).backward()
+        return [o.detach().double().cpu() for o in outs], inp.grad.double().cpu(), {n: p.grad.double().cpu() for n, p in h.named_parameters() if p.grad is not None}
+    exact = run(copy.deepcopy(head).double(), x.double(), [w.double() for w in wts])
+    ours = run(copy.deepcopy(head).to(device), x.to(device).contiguous(memory_format=torch.channels_last_3d), [w.to(device) for w in wts])
+    for a, b in zip(ours[0], exact[0]):
+        assert _rel(a, b) <= 2e-5
+    assert _rel(ours[1], exact[1]) <= 2e-5
+    assert set(ours[2]) == set(exact[2]) and "cls_conv.bias" in ours[2] and "scales.1.scale" in ours[2]
+    for n in exact[2]:
+        assert _rel(ours[2][n], exact[2][n]) <= 5e-5, n

@@ -1,64 +1,101 @@
-"""Training-step timing at BASELINE configs[2] shapes on one GPU (fp32): 50 sampled views -> 10 NeRF target views removed ->
-40 source views 240x320, 40x40x16 voxels, 2048 rays x 64 samples, all five losses, backward, AdamW step.
-Not the headline metric (bench.py is); reports ms/step and the time of the hand-written forward/backward kernels."""
-import os, sys, time, json
+"""Training-step timing at BASELINE configs[2] shapes (SURVEY.md 8d "cfg3"): per rank one scene per step -- 50 sampled views of which
+10 become NeRF targets -> 40 source views 240x320, 40x40x16 voxels, 2048 rays x 64 samples, all five losses, backward, gradient
+clipping, AdamW.  ``--gpus N`` starts N ranks (one process per GPU, DistributedDataParallel over RCCL, nerfdet_amd/train.py);
+the step time is the slowest rank's.  Not the headline metric (bench.py is).  Reports ms/step, scenes/s over all ranks and the
+event-timed forward launches of the packed ray sampler K4 (algorithmic bytes per SURVEY.md 8d) against the HBM roofline.
+
+    python tools/bench_train.py [--gpus N] [--steps K] [--warmup W] [--arith f32|bf16x3|bf16] [--depth-supervise 0|1]
+"""
+import argparse
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from nerfdet_amd.boxes import DepthInstance3DBoxes
-from nerfdet_amd.presets import build_nerfdet
-from nerfdet_amd.synth import ring_scene_meta
-from nerfdet_amd import rays
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def launch(args):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = rc or p.wait()
+    return rc
 
 
 def main():
-    dev = torch.device("cuda")
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--arith", default=None)
+    ap.add_argument("--depth-supervise", type=int, default=1)
+    ap.add_argument("--views", type=int, default=40)
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch(args))
+    from nerfdet_amd import dist as D, rays, trace
+    from nerfdet_amd.presets import build_nerfdet
+    from nerfdet_amd.synth import batch_to, train_scene
+    from nerfdet_amd.train import build_optimizer, train_one_step, wrap_ddp
+    import nerfdet_amd.conv3d as C3
+    rank, world, local = D.init_dist("nccl")
+    dev = torch.device("cuda", local)
+    if args.arith:
+        C3.set_arithmetic(args.arith)
     torch.manual_seed(0)
-    det = build_nerfdet(50, depth_supervise=True)
+    det = build_nerfdet(50, depth_supervise=bool(args.depth_supervise))
     with torch.no_grad():
         det.neck.fpn_convs[0].conv.weight.mul_(1 / 30.0)
         det.nerf_mlp.mlp.sigma_layer.output_layer.bias.fill_(1.0)
     det.to(dev).train()
-    n_v, hw, t_views = 40, (240, 320), 10
-    meta = ring_scene_meta(n_v, hw)
-    g = torch.Generator().manual_seed(0)
-    nray = (hw[0] - 20) * (hw[1] - 20)
-    ang = torch.rand(1, t_views, 1, generator=g) * 2 * np.pi
-    cam = torch.cat([2.5 * torch.cos(ang), 2.5 * torch.sin(ang), 1.2 + 0 * ang], -1)
-    ray_o = cam.unsqueeze(2).expand(1, t_views, nray, 3).contiguous()
-    ray_d = -ray_o / ray_o.norm(dim=-1, keepdim=True) + 0.35 * torch.randn(1, t_views, nray, 3, generator=g)
-    batch = dict(img=torch.randn(1, n_v, 3, *hw, generator=g), img_metas=[meta], denorm_images=torch.rand(1, n_v, 3, *hw, generator=g),
-                 lightpos=ray_o, raydirs=ray_d, gt_images=torch.rand(1, t_views, nray, 3, generator=g),
-                 gt_depths=torch.rand(1, t_views, hw[0] - 20, hw[1] - 20, generator=g) * 5 + 0.5,
-                 nerf_sizes=[torch.tensor([[hw[0] - 20, hw[1] - 20, 3]])])
-    batch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
-    ctr = torch.rand(8, 3, generator=g) * torch.tensor([5.0, 5.0, 1.5]) + torch.tensor([-2.5, -2.5, -0.5])
-    size = 0.6 + torch.rand(8, 3, generator=g)
-    gt_boxes = [DepthInstance3DBoxes(torch.cat([ctr, size], 1), box_dim=6, with_yaw=False, origin=(0.5, 0.5, 0.5)).to(dev)]
-    gt_labels = [torch.randint(0, 18, (8,), generator=g).to(dev)]
-    params = [p for p in det.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=1e-4)
-    data = dict(batch, gt_bboxes_3d=gt_boxes, gt_labels_3d=gt_labels)
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        out = det.train_step(data)
-        out["loss"].backward()
-        torch.nn.utils.clip_grad_norm_(params, 35.0)
-        opt.step()
-        return out
-    for _ in range(3):
-        out = step()
+    model = wrap_ddp(det, dev) if world > 1 else det
+    data = batch_to(train_scene(args.views, (240, 320), t_views=10, n_boxes=8, seed=rank), dev)
+    opt = build_optimizer(model)
+    rec = trace.Recorder()
+    for _ in range(args.warmup):
+        out = train_one_step(model, data, opt)
+    trace.recorder = rec
+    if world > 1:
+        torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 8
-    for _ in range(n):
-        out = step()
+    for _ in range(args.steps):
+        out = train_one_step(model, data, opt)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n
-    print(json.dumps(dict(workload="cfg3 shapes, 1 GPU, fp32: 40 source views, 2048 rays x 64 samples, 5 losses + backward + AdamW",
-                          ms_per_train_step=dt * 1e3, scenes_per_s=1 / dt, log_vars=out["log_vars"],
-                          peak_mem_GB=torch.cuda.max_memory_allocated() / 1e9)))
+    if world > 1:
+        torch.distributed.barrier()
+    dt = D.max_over_ranks((time.perf_counter() - t0) / args.steps, dev)
+    trace.recorder = None
+    if rank == 0:
+        spans = rec.span_ms()
+        k4 = spans.get("k_ray_stats_packed") or spans.get("k_ray_view_stats") or []
+        line = dict(workload=f"cfg3 shapes, {world} GPU(s) x 1 scene/step, {C3.ARITHMETIC} convolutions: {args.views} source views 240x320, 2048 rays x 64 samples, "
+                             f"{'5' if args.depth_supervise else '4'} losses + backward + clip + AdamW" + (", DDP over RCCL" if world > 1 else ""),
+                    n_gpus=world, ms_per_train_step=dt * 1e3, scenes_per_s=world / dt, log_vars=out["log_vars"], grad_norm=out.get("grad_norm"),
+                    peak_mem_GB=torch.cuda.max_memory_allocated() / 1e9)
+        if k4:
+            ms = sorted(m for m, _ in k4)
+            b = k4[0][1]["bytes"]
+            line["roofline_k4_forward"] = dict(kernel="k_ray_stats_packed (K4: Projector.compute + compute_mask_points fused)", bound="hbm",
+                                               algorithmic_bytes=b, median_launch_ms=ms[len(ms) // 2], achieved=b / ms[len(ms) // 2] / 1e6,
+                                               peak=8000.0, unit="GB/s", frac=b / ms[len(ms) // 2] / 1e6 / 8000.0)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

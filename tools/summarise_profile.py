@@ -30,8 +30,8 @@ def find(d, pat):
     return hits[0]
 
 
-def stats(trace_dir, out_csv, header=""):
-    rows = list(csv.DictReader(open(find(trace_dir, "*kernel_trace.csv"))))
+def stats(trace_dir, out_csv, header="", exclude=()):
+    rows = [r for r in csv.DictReader(open(find(trace_dir, "*kernel_trace.csv"))) if not any(e in r["Kernel_Name"] for e in exclude)]
     agg = OrderedDict()
     for r in rows:
         k = short(r["Kernel_Name"])
@@ -84,7 +84,9 @@ def pmc(fetch_dir, write_dir, out_json, command="", workload="cfg2", algorithmic
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "stats":
-        stats(sys.argv[2], sys.argv[3], header=" ".join(sys.argv[4:]))
+        # --exclude=a,b drops kernels whose name contains a or b (e.g. MIOpen's find-mode trial kernels "naive_conv" of the warm-up)
+        ex = [a.split("=", 1)[1].split(",") for a in sys.argv[4:] if a.startswith("--exclude=")]
+        stats(sys.argv[2], sys.argv[3], header=" ".join(a for a in sys.argv[4:] if not a.startswith("--exclude=")), exclude=ex[0] if ex else ())
     elif mode == "pmc":
         extra = sys.argv[5:]
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], command=extra[0] if extra else "",
