@@ -230,7 +230,7 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the static part of the step from hipGraphs (nerfdet_amd/graphed.py); measured equal to eager "
                          "launches within 1 %% on MI355X: the step is GPU-bound, launch-ahead already hides the gaps")
-    ap.add_argument("--conv-arithmetic", default=None, choices=["f32", "bf16x3"],
+    ap.add_argument("--conv-arithmetic", default=None, choices=["f32", "bf16x3", "bf16"],
                     help="convolution kernel family (default: the package default, nerfdet_amd.conv3d.ARITHMETIC)")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -314,7 +314,12 @@ def main():
         stages = rec.stage_ms()
         traffic, traffic_src = measured_traffic(args.workload)
         bf16x3 = C3.ARITHMETIC == "bf16x3"
-        if bf16x3:
+        if C3.ARITHMETIC == "bf16":
+            conv_kernel = ("k_conv_split in its one-product mode (implicit-GEMM convolution, both operands rounded to bf16, one bf16 MFMA product per "
+                           "multiply, fp32 accumulate, fp32 activations in HBM): 3D neck + head, ResNet/FPN; all tile instantiations")
+            conv_peak = MFMA_BF16_PEAK_TFLOPS
+            conv_peak_note = "achieved = algorithmic convolution FLOPs / time; peak = dense bf16 MFMA peak 2500 TFLOP/s"
+        elif bf16x3:
             conv_kernel = ("k_conv_split (implicit-GEMM convolution on the bf16 matrix cores, fp32 operands split exactly into 3 bf16 terms, "
                            "6 MFMA products per multiply, fp32 accumulate: 3D neck + head, ResNet/FPN; all tile instantiations, split-K "
                            "reduce launches included in the event spans)")
@@ -359,11 +364,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if not bf16x3 else "f32 (convolutions: fp32 operands as exact 3-term bf16 sums on the bf16 MFMA, fp32 accumulate)",
+            "dtype": {"f32": "f32", "bf16x3": "f32 (convolutions: fp32 operands as exact 3-term bf16 sums on the bf16 MFMA, fp32 accumulate)",
+                      "bf16": "bf16 (convolution operands rounded to bf16 on the MFMA, fp32 accumulate; activations, projection, aggregation, "
+                              "NMS fp32 -- SURVEY.md 0.1)"}[C3.ARITHMETIC],
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: nerfdet_res{w['depth']}_2x_low_res forward_test, {w['n_views']} views "
-                                   f"{w['img_hw'][0]}x{w['img_hw'][1]}, {'x'.join(map(str, w['n_voxels']))} voxels, fp32, "
-                                   f"1 scene/step/GPU, random-init weights",
+                                   f"{w['img_hw'][0]}x{w['img_hw'][1]}, {'x'.join(map(str, w['n_voxels']))} voxels, "
+                                   f"{'bf16 convolutions' if C3.ARITHMETIC == 'bf16' else 'fp32'}, 1 scene/step/GPU, random-init weights",
                        "scenes_per_step": world, "parallelism": f"scene replicas x{world} (no data-path collective)"},
             "roofline": {"kernel": f"{dom_name} (the convolution instantiation with the largest share of the step; event spans include the "
                                    f"split-K reduce launch where a layer splits K)",

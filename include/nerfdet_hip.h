@@ -244,6 +244,15 @@ int ndet_conv_ndhwc_split(const float* in, const uint16_t* w_planes, float* out,
                           const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
                           void* workspace, void* stream);
 
+/* The same convolution with both operands rounded to bf16 and ONE MFMA product per multiply (fp32 accumulate, fp32 activations in
+ * HBM): the "bf16" arithmetic BASELINE.json's configs 3 and 5 name -- what torch.autocast(bfloat16) would run nn.Conv3d / nn.Conv2d
+ * of mmdet3d/models/necks/imvoxelnet.py:22-67,233-260 and the ResNet/FPN layers in.  Same arguments and weight planes as
+ * ndet_conv_ndhwc_split (only the first plane is multiplied). */
+int ndet_conv_ndhwc_bf16(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
+                         const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
+                         const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
+                         void* workspace, void* stream);
+
 /* ResNet stem tail in one pass: BatchNorm(eval) as per-channel scale/shift + ReLU + MaxPool(3, stride 2, pad 1) on the
  * channels-last stem output x (N,H,W,C), C % 4 == 0 -> out (N, (H-1)/2+1, (W-1)/2+1, C).  Third-party mmdet ResNet stem
  * (SURVEY.md appendix C), called at mmdet3d/models/detectors/nerfdet.py:140. */

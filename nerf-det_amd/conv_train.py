@@ -42,7 +42,7 @@ def _train_pack(w: Tensor, kernel, adjoint: bool) -> dict:
     taps = 1
     for v in kernel:
         taps *= int(v)
-    if C.ARITHMETIC != "bf16x3":
+    if C.ARITHMETIC not in ("bf16x3", "bf16"):
         if not adjoint:
             return _raw_pack(C.pack_weight(w), kernel)
         flip = w.flip(tuple(range(2, w.dim()))).transpose(0, 1)

@@ -287,6 +287,7 @@ extern "C" int ndet_conv_ndhwc(const float* in, const float* w_packed, float* ou
         NDET_REQUIRE(kernel[a] >= 1 && kernel[a] <= 7 && stride[a] >= 1 && stride[a] <= 4 && pad[a] >= 0 && pad[a] < kernel[a], NDET_E_UNSUPPORTED,
                      "%s: kernel/stride/pad out of range on axis %d", fn, a);
     Conv3dParams p;
+    p.max_order = 2;
     p.in = in; p.w = w_packed; p.out = out; p.scale = scale; p.shift = shift; p.res = residual; p.partial = (float*)workspace;
     p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu; p.transposed = 0;
     p.kd = kernel[0]; p.kh = kernel[1]; p.kw = kernel[2];
@@ -332,6 +333,7 @@ extern "C" int ndet_conv3d_ndhwc(const float* in, const float* w_packed, float* 
     NDET_REQUIRE((((uintptr_t)in | (uintptr_t)w_packed) & 15) == 0, NDET_E_UNSUPPORTED, "%s: in / weights must be 16-byte aligned", fn);
     NDET_REQUIRE(ksize == 2 && stride == 2, NDET_E_UNSUPPORTED, "%s: transposed conv supports kernel 2 stride 2 only", fn);
     Conv3dParams p;
+    p.max_order = 2;
     p.in = in; p.w = w_packed; p.out = out; p.scale = scale; p.shift = shift; p.res = residual; p.partial = nullptr;
     p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu; p.transposed = 1;
     p.kd = p.kh = p.kw = 2; p.sd = p.sh = p.sw = 2; p.pd = p.ph = p.pw = 0;

@@ -24,6 +24,8 @@ struct Conv3dParams {
     int M;                // GEMM rows: output voxels (input voxels when transposed)
     int res_up2;          // 1: residual is a (OD, ceil(OH/2), ceil(OW/2), Cout) map read at (d, h>>1, w>>1): nearest x2 upsample-add
     int RH, RW;           //    its H and W
+    int max_order;        // bf16x3 kernels: products (pa, pb) with pa + pb <= max_order are issued -- 2: all six (fp32-class result),
+                          // 0: a0*b0 only = both operands rounded to bf16, fp32 accumulate (the "bf16" arithmetic of BASELINE configs 3/5)
 };
 
 // internal launchers (one per kernel family) and the shared split-K reduction

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
             // smallest terms first; the (pa, pb) pairs with pa + pb <= 2
 #pragma unroll
             for (int order = 2; order >= 0; --order)
+                if (order <= p.max_order)
 #pragma unroll
                 for (int pa = 0; pa <= order; ++pa) {
                     const int pb = order - pa;
@@ -468,6 +469,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
                 }
 #pragma unroll
                 for (int order = 2; order >= 0; --order)
+                    if (order <= p.max_order)
 #pragma unroll
                     for (int pa = 0; pa <= order; ++pa) {
                         const int pb = order - pa;
@@ -739,6 +741,7 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
                     for (int tb = 0; tb < NT16; ++tb) fb[pl][tb] = *reinterpret_cast<const bf16x8*>(bst + pl * BPL + tb * 16 * CBK);
 #pragma unroll
                 for (int order = 2; order >= 0; --order)
+                    if (order <= p.max_order)
 #pragma unroll
                     for (int pa = 0; pa <= order; ++pa) {
                         const int pbb = order - pa;
@@ -937,11 +940,31 @@ extern "C" int ndet_split_weights_bf16x3_torch(const float* w_torch, int taps, i
     return NDET_OK;
 }
 
+static int conv_split_entry(const char* fn, int max_order, const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin,
+                            int Cout, const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
+                            const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile, void* workspace,
+                            void* stream);
+
 extern "C" int ndet_conv_ndhwc_split(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
                                      const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
                                      const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
                                      void* workspace, void* stream) {
-    const char* fn = "ndet_conv_ndhwc_split";
+    return conv_split_entry("ndet_conv_ndhwc_split", 2, in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, transposed, scale, shift, residual,
+                            residual_up2, relu, splits, tile, workspace, stream);
+}
+
+extern "C" int ndet_conv_ndhwc_bf16(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
+                                    const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
+                                    const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
+                                    void* workspace, void* stream) {
+    return conv_split_entry("ndet_conv_ndhwc_bf16", 0, in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, transposed, scale, shift, residual,
+                            residual_up2, relu, splits, tile, workspace, stream);
+}
+
+static int conv_split_entry(const char* fn, int max_order, const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin,
+                            int Cout, const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
+                            const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile, void* workspace,
+                            void* stream) {
     NDET_REQUIRE(in && w_planes && out && kernel && stride && pad, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
     NDET_REQUIRE((scale == nullptr) == (shift == nullptr), NDET_E_INVALID, "%s: scale and shift go together", fn);
@@ -952,6 +975,7 @@ extern "C" int ndet_conv_ndhwc_split(const float* in, const uint16_t* w_planes, 
     p.in = in; p.w = reinterpret_cast<const float*>(w_planes); p.out = out; p.scale = scale; p.shift = shift; p.res = residual;
     p.partial = (float*)workspace;
     p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
+    p.max_order = max_order;
     if (transposed) {
         for (int a = 0; a < 3; ++a)
             NDET_REQUIRE(kernel[a] == 2 && stride[a] == 2 && pad[a] == 0, NDET_E_UNSUPPORTED, "%s: transposed conv supports kernel 2 stride 2 pad 0 only", fn);

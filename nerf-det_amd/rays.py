@@ -288,3 +288,11 @@ def render_rays(ray_batch, mean_volume, cov_volume, features_2D, img, aabb, near
                 "gt_rgb": gt_rgb.view(view_num, hh, ww, 3),
                 "gt_depth": gt_depth.view(view_num, hh, ww, 1) if gt_depth is not None else None}
     return None
+
+
+def compute_psnr(pred: Tensor, target: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+    """PSNR of a rendered view against its ground truth, maximum pixel value 1: ``-10 log10(mean((pred - target)^2))``
+    (model_utils/save_rendered_img.py:10-19; the image dump and SSIM of that module are visualisation, out of scope)."""
+    if mask is not None:
+        pred, target = pred[mask], target[mask]
+    return -10.0 * torch.log(((pred - target) ** 2).mean()) / float(np.log(10.0))

@@ -45,6 +45,8 @@ BACKBONES = Registry("backbone")
 NECKS = Registry("neck")
 HEADS = Registry("head")
 LOSSES = Registry("loss")
+PIPELINES = Registry("pipeline")
+DATASETS = Registry("dataset")
 
 
 def build_backbone(cfg):
@@ -67,3 +69,14 @@ def build_detector(cfg, train_cfg=None, test_cfg=None):
     """mmdet3d/models/builder.py: build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)."""
     from . import detector, backbone, neck3d, head, losses  # noqa: F401  (populate the registries)
     return DETECTORS.build(cfg, train_cfg=train_cfg, test_cfg=test_cfg)
+
+
+def build_pipeline(cfg):
+    from . import datasets  # noqa: F401  (populates the registry)
+    return PIPELINES.build(cfg)
+
+
+def build_dataset(cfg, default_args=None):
+    """mmdet3d/datasets/builder.py: build_dataset(cfg.data.train / .val / .test)."""
+    from . import datasets  # noqa: F401
+    return DATASETS.build(cfg, **(default_args or {}))

@@ -308,6 +308,47 @@ def make_ray_select_fixture(ref, name):
     npz(name, **arrays)
 
 
+def make_render_testing_fixture(ref, name):
+    """f-4: the novel-view path, render_rays(render_testing=True) (render_ray.py:452-517): every ray of the target views in chunks
+    of N_rand, deterministic sampling; plus compute_psnr of save_rendered_img.py:10-19 restated inline (that module needs cv2 /
+    skimage / imageio at import time; PSNR is -10 log10(mse))."""
+    torch.manual_seed(21)
+    n_v, d, h, w, width = 6, 8, 48, 64, 32
+    meta = O.ring_scene_meta(n_v, (h, w))
+    mlp = ref.nerf_mlp.VanillaNeRFRadianceField(net_depth=4, net_width=width, skip_layer=3, feature_dim=2 * (d + 3),
+                                                net_depth_condition=1, net_width_condition=width // 2)
+    with torch.no_grad():
+        for p in mlp.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    mlp.eval()
+    feat2d = torch.randn(n_v, d, h // 4, w // 4)
+    img = torch.rand(n_v, 3, h, w)
+    t_views, rh, rw = 2, 7, 9                       # 63 rays per view, chunks of 16: ragged last chunk, chunks straddle views
+    ang = torch.rand(1, t_views, 1) * 2 * np.pi
+    cam = torch.cat([2.0 * torch.cos(ang), 2.0 * torch.sin(ang), 1.0 + 0 * ang], -1)
+    ray_o = cam.unsqueeze(2).expand(1, t_views, rh * rw, 3).contiguous()
+    ray_d = -ray_o / ray_o.norm(dim=-1, keepdim=True) + 0.3 * torch.randn(1, t_views, rh * rw, 3)
+    gt_rgb = torch.rand(1, t_views, rh * rw, 3)
+    gt_depth = torch.rand(1, t_views, rh, rw) * 5 + 0.5
+    rb = dict(ray_o=ray_o, ray_d=ray_d, gt_rgb=gt_rgb, gt_depth=gt_depth, nerf_sizes=[torch.tensor([[rh, rw, 3]])])
+    import contextlib
+    import io
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):          # the reference prints gt_rgb.shape
+        ret = ref.render_ray.render_rays(rb, None, None, feat2d, img, None, [0.2, 8.0], 12, 16, mlp, meta, ref.projection.Projector(), "image",
+                                         is_train=False, render_testing=True)
+        ret_nodepth = ref.render_ray.render_rays(dict(rb, gt_depth=[]), None, None, feat2d, img, None, [0.2, 8.0], 12, 16, mlp, meta,
+                                                 ref.projection.Projector(), "image", is_train=False, render_testing=True)
+    rgb, gt = ret["outputs_coarse"]["rgb"], ret["gt_rgb"]
+    psnr = torch.stack([-10.0 * torch.log(((rgb[v] - gt[v]) ** 2).mean()) / np.log(10.0) for v in range(t_views)])
+    assert ret_nodepth["gt_depth"] is None and torch.equal(ret_nodepth["outputs_coarse"]["rgb"], rgb)
+    arrays = dict(features_2d=feat2d, img=img, ray_o=ray_o, ray_d=ray_d, gt_rgb=gt_rgb, gt_depth=gt_depth, n_samples=np.array(12), n_rand=np.array(16),
+                  nerf_size=np.array([rh, rw, 3]), out_rgb=rgb, out_depth=ret["outputs_coarse"]["depth"], out_gt_rgb=gt, out_gt_depth=ret["gt_depth"],
+                  psnr=psnr, **meta_arrays(meta))
+    arrays.update(sd_arrays("nerf_mlp.", mlp))
+    npz(name, **arrays)
+
+
 def make_head_fixture(ref, name, seed, c_in, c_mid, grid):
     """A13-A15: FastIndoorImVoxelNeck, ScanNetImVoxelHeadV2 forward + get_bboxes (+NMS)."""
     torch.manual_seed(seed)
@@ -395,6 +436,7 @@ def main():
     make_ray_fixture(ref, "rays_small_s0", 0, n_v=6, d=8, img_hw=(60, 80), n_rays=32, n_samples=16, width=32)
     make_ray_fixture(ref, "rays_small_s1", 1, n_v=9, d=32, img_hw=(60, 80), n_rays=24, n_samples=64, width=64)
     make_ray_select_fixture(ref, "rays_select")
+    make_render_testing_fixture(ref, "render_testing")
     make_head_fixture(ref, "head_small_s0", 0, c_in=8, c_mid=8, grid=(8, 8, 4))
     make_nms_fixture(ref, "nms_random")
 

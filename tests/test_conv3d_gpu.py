@@ -313,3 +313,32 @@ def test_resnet_fpn_hip_matches_library(device):
     net.train()
     y = net(x.requires_grad_(True))
     assert y[-1].requires_grad
+
+
+@pytest.mark.parametrize("cin,cout,grid,k,relu,use_res,tile", [(64, 96, (10, 9, 7), 3, 1, True, 0), (256, 256, (16, 16, 8), 3, 0, False, 3257),
+                                                               (128, 64, (1, 24, 20), 1, 1, False, 0), (256, 128, (12, 12, 8), 3, 1, False, 128256)])
+def test_bf16_arithmetic_is_a_bf16_rounded_convolution(device, cin, cout, grid, k, relu, use_res, tile):
+    """``set_arithmetic("bf16")``: exactly the convolution of the bf16-ROUNDED operands accumulated in fp32 (what bf16 autocast
+    computes) -- checked against PyTorch-CPU fp32 on operands rounded the same way; and measurably different from the fp32 result,
+    so the mode really drops the residual products."""
+    from nerfdet_amd import conv3d
+    torch.manual_seed(cin + cout)
+    conv = torch.nn.Conv3d(cin, cout, k, 1, k // 2, bias=False)
+    x = torch.randn(*grid, cin)
+    res = torch.randn(*grid, cout) if use_res else None
+    xr, wr = x.bfloat16().float(), conv.weight.detach().bfloat16().float()
+    ref = torch.nn.functional.conv3d(xr.permute(3, 0, 1, 2).unsqueeze(0), wr, padding=k // 2)[0].permute(1, 2, 3, 0)
+    full = torch.nn.functional.conv3d(x.permute(3, 0, 1, 2).unsqueeze(0), conv.weight.detach(), padding=k // 2)[0].permute(1, 2, 3, 0)
+    if res is not None:
+        ref, full = ref + res, full + res
+    if relu:
+        ref, full = ref.relu(), full.relu()
+    conv.to(device)
+    prev = conv3d.set_arithmetic("bf16")
+    try:
+        got = conv3d.conv3d_ndhwc(x.to(device), conv3d.packed([conv]), residual=None if res is None else res.to(device), relu=relu, tile=tile).cpu()
+    finally:
+        conv3d.set_arithmetic(prev)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-5 * scale
+    assert float((got - full).abs().max()) >= 1e-4 * scale

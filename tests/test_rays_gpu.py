@@ -167,6 +167,29 @@ def test_ray_stats_training_size_vs_oracle_and_properties(device):
     torch.testing.assert_close(glob_p, glob, rtol=0, atol=ATOL)
 
 
+def test_render_testing_matches_reference_golden(device):
+    """f-4: ``render_rays(render_testing=True)`` (render_ray.py:452-517) against the reference's own output -- every ray of two target
+    views in chunks of N_rand = 16 (ragged last chunk, chunks straddling the view boundary), colours, depths, shapes, the
+    no-depth variant, and the PSNR of save_rendered_img.py:10-19."""
+    from nerfdet_amd import rays
+    g = load_golden("render_testing")
+    mlp = _mlp(g, device)
+    rh, rw = int(g["nerf_size"][0]), int(g["nerf_size"][1])
+    rb = dict(ray_o=g["ray_o"].to(device), ray_d=g["ray_d"].to(device), gt_rgb=g["gt_rgb"].to(device), gt_depth=g["gt_depth"].to(device),
+              nerf_sizes=[torch.tensor([[rh, rw, 3]])])
+    args = (g["features_2d"].to(device), g["img"].to(device), None, [0.2, 8.0], int(g["n_samples"]), int(g["n_rand"]), mlp, golden_meta(g), None, "image")
+    with torch.no_grad():
+        ret = rays.render_rays(rb, None, None, *args, is_train=False, render_testing=True)
+        ret2 = rays.render_rays(dict(rb, gt_depth=[]), None, None, *args, is_train=False, render_testing=True)
+    assert ret["outputs_coarse"]["rgb"].shape == (2, rh, rw, 3) and ret["outputs_coarse"]["depth"].shape == (2, rh, rw, 1)
+    torch.testing.assert_close(ret["outputs_coarse"]["rgb"].cpu(), g["out_rgb"], rtol=1e-5, atol=ATOL)
+    torch.testing.assert_close(ret["outputs_coarse"]["depth"].cpu(), g["out_depth"], rtol=1e-5, atol=ATOL)
+    assert torch.equal(ret["gt_rgb"].cpu(), g["out_gt_rgb"]) and torch.equal(ret["gt_depth"].cpu(), g["out_gt_depth"])
+    assert ret2["gt_depth"] is None and torch.equal(ret2["outputs_coarse"]["rgb"], ret["outputs_coarse"]["rgb"])
+    psnr = torch.stack([rays.compute_psnr(ret["outputs_coarse"]["rgb"][v], ret["gt_rgb"][v]) for v in range(2)])
+    torch.testing.assert_close(psnr.cpu(), g["psnr"], rtol=1e-4, atol=1e-4)
+
+
 def test_render_testing_chunks_equal_one_pass(device):
     """render_rays(render_testing=True) (render_ray.py:452-517): every ray of the target views, chunks of N_rand,
     deterministic sampling -- equals one render_rays_func over all rays, reshaped to (views, H, W, .)."""
