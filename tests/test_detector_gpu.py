@@ -51,8 +51,19 @@ def test_nms_random_golden_and_edges(device):
     # idempotence: NMS of the survivors keeps all of them, in order
     again = aligned_3d_nms(bb[ref].to(device), ss[ref].to(device), cc[ref].to(device), 0.25)
     assert torch.equal(again.cpu(), torch.arange(len(ref)))
-    with pytest.raises(ValueError):
-        aligned_3d_nms(torch.zeros(5000, 6, device=device), torch.zeros(5000, device=device), torch.zeros(5000, dtype=torch.long, device=device), 0.25)
+    # more candidates than one launch takes (nms_pre <= 0 hands the NMS every voxel): windowed, same picks as the sequential loop
+    g2 = torch.Generator().manual_seed(7)
+    n = 9000
+    ctr = torch.rand(n, 3, generator=g2) * torch.tensor([6.4, 6.4, 3.2])
+    size = 0.6 + torch.rand(n, 3, generator=g2)
+    bb = torch.cat([ctr - size / 2, ctr + size / 2], 1)
+    ss = torch.rand(n, generator=g2)
+    cc = torch.randint(0, 3, (n,), generator=g2)
+    ref = O.aligned_3d_nms(bb, ss, cc, 0.25)
+    got = aligned_3d_nms(bb.to(device), ss.to(device), cc.to(device), 0.25)
+    assert torch.equal(got.cpu(), ref) and 1000 < len(ref) < 4096
+    with pytest.raises(ValueError):      # more survivors than one launch can carry: refused loudly, never truncated
+        aligned_3d_nms(torch.cat([ctr - 0.01, ctr + 0.01], 1).to(device), ss.to(device), cc.to(device), 0.25)
 
 
 def test_neck_and_head_match_reference_golden(device):

@@ -1,0 +1,34 @@
+"""Scratch (GPU box): per-launch event timing of one cfg2 forward_test, in launch order, averaged over a few steps."""
+import os, sys, json
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from nerfdet_amd import trace
+
+w = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
+dev = torch.device("cuda")
+det = bench.build_model(w).to(dev)
+batch = bench.to_device(bench.synth_batch(w, 0), dev)
+with torch.no_grad():
+    for _ in range(4):
+        det(return_loss=False, **batch)
+    steps = 6
+    recs = []
+    for _ in range(steps):
+        r = trace.Recorder()
+        trace.recorder = r
+        det(return_loss=False, **batch)
+        trace.recorder = None
+        torch.cuda.synchronize()
+        recs.append([(n, a.elapsed_time(b), i) for n, a, b, i in r.spans])
+n = len(recs[0])
+assert all(len(r) == n for r in recs)
+tot = 0.0
+print(f"{'#':>3} {'kernel':32s} {'ms':>7s} {'GF':>7s} {'MB':>7s} {'TF/s':>6s} {'GB/s':>6s}")
+for i in range(n):
+    name, _, info = recs[0][i]
+    ms = sorted(r[i][1] for r in recs)[steps // 2]
+    tot += ms
+    fl, by = info.get("flops", 0), info.get("bytes", 0)
+    print(f"{i:3d} {name[:32]:32s} {ms:7.3f} {fl / 1e9:7.1f} {by / 1e6:7.1f} {fl / ms / 1e9 if fl else 0:6.1f} {by / ms / 1e6:6.0f}")
+print("sum of spans", round(tot, 3), "ms")
