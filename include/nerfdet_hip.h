@@ -253,6 +253,16 @@ int ndet_conv_ndhwc_bf16(const float* in, const uint16_t* w_planes, float* out, 
                          const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
                          void* workspace, void* stream);
 
+/* Experimental fp32-class arithmetic for the halo-stationary tiles (stride-1 same-padded multi-tap layers: the 3x3 / 3x3x3
+ * convolutions of mmdet3d/models/necks/imvoxelnet.py:22-67,233-260 and of the FPN / ResNet): operands as fp16 PAIRS, three MFMA
+ * products per multiply instead of six.  The caller pre-scales both tensors by powers of two towards 2^15 (weights: `scale` of
+ * ndet_split_weights_f16x2; activations: `xscale`, applied while they are split) and folds 1 / (xscale * weight scale) into the
+ * epilogue's `scale`.  tile: 4128 / 4256 / 4257 (= 3128 / 3256 / 3257 on two planes). */
+int ndet_split_weights_f16x2(const float* w_packed, int taps, int Cout, int Cin, float scale, uint16_t* planes, void* stream);
+int ndet_conv_ndhwc_f16x2(const float* in, const uint16_t* w_planes_f16, float* out, int D, int H, int W, int Cin, int Cout,
+                          const int* kernel, const int* stride, const int* pad, const float* scale, const float* shift,
+                          const float* residual, int relu, int splits, int tile, float xscale, void* workspace, void* stream);
+
 /* ResNet stem tail in one pass: BatchNorm(eval) as per-channel scale/shift + ReLU + MaxPool(3, stride 2, pad 1) on the
  * channels-last stem output x (N,H,W,C), C % 4 == 0 -> out (N, (H-1)/2+1, (W-1)/2+1, C).  Third-party mmdet ResNet stem
  * (SURVEY.md appendix C), called at mmdet3d/models/detectors/nerfdet.py:140. */

@@ -26,6 +26,8 @@ struct Conv3dParams {
     int RH, RW;           //    its H and W
     int max_order;        // bf16x3 kernels: products (pa, pb) with pa + pb <= max_order are issued -- 2: all six (fp32-class result),
                           // 0: a0*b0 only = both operands rounded to bf16, fp32 accumulate (the "bf16" arithmetic of BASELINE configs 3/5)
+    float xscale;         // fp16-pair tiles: power of two the activations are multiplied by while they are split (its inverse, and the
+                          // weight scale's, are folded into `scale` by the caller)
 };
 
 // internal launchers (one per kernel family) and the shared split-K reduction

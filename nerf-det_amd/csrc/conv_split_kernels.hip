@@ -56,7 +56,33 @@ __device__ __forceinline__ void spl_split4(const float4 v, uint2& p0, uint2& p1,
     p2 = make_uint2(o2[0], o2[1]);
 }
 
-template <int BM, int BN, int WGM, int WGN>
+// fp16 pair scheme (SCH 1 of the halo tiles): with the tensor pre-scaled by a power of two so that its largest magnitude sits near
+// 2^15, x = hi + lo with hi = fp16(x), lo = fp16(x - hi): 2 x 11 significand bits, both halves in fp16's normal range for every
+// element above ~4e-6 of the tensor's maximum.  a*b ~ hi_a hi_b + hi_a lo_b + lo_a hi_b (each product exact in fp32); the dropped
+// lo_a lo_b and the rounding of the lo halves are <= 3 x 2^-22 |ab| -- below the rounding noise a K >= 64 fp32 accumulation carries.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t spl_pack_f16(float x, float y) {
+    const f16x2v v = __builtin_convertvector((f32x2){x, y}, f16x2v);
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float spl_f16_lo(uint32_t u) { return (float)__builtin_bit_cast(f16x2v, u)[0]; }
+__device__ __forceinline__ float spl_f16_hi(uint32_t u) { return (float)__builtin_bit_cast(f16x2v, u)[1]; }
+__device__ __forceinline__ void spl_split4_f16(const float4 v, float scale, uint2& p0, uint2& p1) {
+    const float x[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
+    uint32_t o0[2], o1[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        o0[i] = spl_pack_f16(a, b);
+        o1[i] = spl_pack_f16(a - spl_f16_lo(o0[i]), b - spl_f16_hi(o0[i]));   // the differences are exact in fp32
+    }
+    p0 = make_uint2(o0[0], o0[1]);
+    p1 = make_uint2(o1[0], o1[1]);
+}
+
+// ONE: the leading bf16 plane only, one product per multiply (bf16 autocast arithmetic).
+template <int BM, int BN, int WGM, int WGN, bool ONE = false>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dParams p, const uint16_t* __restrict__ wsplit) {
     constexpr int NTHR = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN;   // per-wave tile
@@ -67,8 +93,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
     static_assert(AR >= 1 && BR >= 1 && MT >= 1 && NT >= 1, "tile too small for the thread count");
     constexpr int APL = BM * SPL_RS, BPL = BN * SPL_RS;  // one plane, in bf16 elements
     extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
-    uint16_t* As = lds16;             // [3][BM][SPL_RS]
-    uint16_t* Bs = lds16 + 3 * APL;   // [3][BN][SPL_RS]
+    constexpr int NPL = ONE ? 1 : 3;
+    uint16_t* As = lds16;               // [NPL][BM][SPL_RS]
+    uint16_t* Bs = lds16 + NPL * APL;   // [NPL][BN][SPL_RS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -112,7 +139,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     float4 ra[AR];
-    uint4 rb[BR][3];
+    uint4 rb[BR][NPL];
     const int64_t wtile = (int64_t)p.Cout * CBK;   // one plane of one K step, in elements
     bool bok[BR];
 #pragma unroll
@@ -151,7 +178,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
 #pragma unroll
         for (int i = 0; i < BR; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NPL; ++pl) {
                 const uint4 v = *reinterpret_cast<const uint4*>(bok[i] ? bt + pl * wtile + (int64_t)RPB * i * CBK : wsplit + bkg * 8);
                 rb[i][pl] = bok[i] ? v : make_uint4(0u, 0u, 0u, 0u);
             }
@@ -167,17 +194,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             uint2 s0, s1, s2;
-            spl_split4(ra[i], s0, s1, s2);
+            if (ONE) s0 = make_uint2(spl_pack(ra[i].x, ra[i].y), spl_pack(ra[i].z, ra[i].w));
+            else spl_split4(ra[i], s0, s1, s2);
             uint16_t* dst = As + (arow_ + RPA * i) * SPL_RS + akq * 4;
             *reinterpret_cast<uint2*>(dst) = s0;
-            *reinterpret_cast<uint2*>(dst + APL) = s1;
-            *reinterpret_cast<uint2*>(dst + 2 * APL) = s2;
+            if (!ONE) {
+                *reinterpret_cast<uint2*>(dst + APL) = s1;
+                *reinterpret_cast<uint2*>(dst + 2 * APL) = s2;
+            }
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
             uint16_t* dst = Bs + (brow_ + RPB * i) * SPL_RS + bkg * 8;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint4*>(dst + pl * BPL) = rb[i][pl];
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint4*>(dst + pl * BPL) = rb[i][pl];
         }
     };
 
@@ -196,9 +226,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
         if (more) load_tile();
 #pragma unroll
         for (int ks = 0; ks < CBK / 16; ++ks) {
-            bf16x8 fa[3][MT], fb[3][NT];
+            bf16x8 fa[NPL][MT], fb[NPL][NT];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t) fa[pl][t] = *reinterpret_cast<const bf16x8*>(abase + pl * APL + t * 32 * SPL_RS + ks * 16);
 #pragma unroll
@@ -206,7 +236,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
             }
             // smallest terms first; the (pa, pb) pairs with pa + pb <= 2
 #pragma unroll
-            for (int order = 2; order >= 0; --order)
+            for (int order = NPL - 1; order >= 0; --order)
                 if (order <= p.max_order)
 #pragma unroll
                 for (int pa = 0; pa <= order; ++pa) {
@@ -276,9 +306,12 @@ __device__ __forceinline__ void spl_dma16(__amdgpu_buffer_rsrc_t rsrc, uint16_t*
 #define WS_DEPTH 2
 #define WS_OOB 0x80000000u
 
+// ONE: the leading bf16 plane only, one product per multiply (bf16 autocast arithmetic); the weight tensor keeps its three planes.
+template <bool ONE>
 __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, const uint16_t* __restrict__ wsplit) {
     constexpr int APL = WS_BM * CBK, BPL = WS_BN * CBK;   // one plane, in bf16 elements
-    constexpr int STAGE = 3 * (APL + BPL);
+    constexpr int NPL = ONE ? 1 : 3;
+    constexpr int STAGE = NPL * (APL + BPL);
     constexpr int AR = 4, BR = 4;                          // rows per producer thread: A 128 / 32, B 256 / 64
     extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
 
@@ -377,11 +410,11 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
                 const int tap = p.transposed ? ztap : (bkd * wkh + bkh) * wkw + bkw;
                 soff = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)tap * cin_steps + bcs) * 3) * wtile_b);
             }
-            uint16_t* stage = lds16 + (u & 1) * STAGE + 3 * APL;
+            uint16_t* stage = lds16 + (u & 1) * STAGE + NPL * APL;
 #pragma unroll
             for (int i = 0; i < BR; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NPL; ++pl)
                     spl_dma16(bres, stage + pl * BPL + (64 * i + pw4 * 16) * CBK, bvoff[i], __builtin_amdgcn_readfirstlane(soff + pl * wtile_b));
             if (live) {
                 if (++bkw == wkw) {
@@ -419,10 +452,14 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
             for (int i = 0; i < AR; ++i) {
                 const u32x4 u = ra[slot][i];
                 uint2 s0, s1, s2;
-                spl_split4(make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)), s0, s1, s2);
+                const float4 xv = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+                if (ONE) s0 = make_uint2(spl_pack(xv.x, xv.y), spl_pack(xv.z, xv.w));
+                else spl_split4(xv, s0, s1, s2);
                 *reinterpret_cast<uint2*>(base + adst[i]) = s0;
-                *reinterpret_cast<uint2*>(base + adst[i] + APL * 2) = s1;
-                *reinterpret_cast<uint2*>(base + adst[i] + APL * 4) = s2;
+                if (!ONE) {
+                    *reinterpret_cast<uint2*>(base + adst[i] + APL * 2) = s1;
+                    *reinterpret_cast<uint2*>(base + adst[i] + APL * 4) = s2;
+                }
             }
         };
 
@@ -454,21 +491,21 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
         const int frow = lane & 15, fc = lane >> 4;
         const int kc = (fc ^ ws_swz(frow)) * 8;                 // (row >> 2) & 3 is the same for every 16-row tile
         const int aoff = (wm * 64 + frow) * CBK + kc;
-        const int boff = 3 * APL + (wn * 128 + frow) * CBK + kc;
+        const int boff = NPL * APL + (wn * 128 + frow) * CBK + kc;
         __syncthreads();
         for (int j = 0; j < n_round; ++j) {
             if (j < n_it) {
                 const uint16_t* st = lds16 + (j & 1) * STAGE;
-                bf16x8 fa[3][4], fb[3][8];
+                bf16x8 fa[NPL][4], fb[NPL][8];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
+                for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) fa[pl][t] = *reinterpret_cast<const bf16x8*>(st + aoff + pl * APL + t * 16 * CBK);
 #pragma unroll
                     for (int t = 0; t < 8; ++t) fb[pl][t] = *reinterpret_cast<const bf16x8*>(st + boff + pl * BPL + t * 16 * CBK);
                 }
 #pragma unroll
-                for (int order = 2; order >= 0; --order)
+                for (int order = NPL - 1; order >= 0; --order)
                     if (order <= p.max_order)
 #pragma unroll
                     for (int pa = 0; pa <= order; ++pa) {
@@ -511,14 +548,19 @@ static int split_launch_ws(const Conv3dParams& p, hipStream_t st, const char* fn
                  NDET_E_UNSUPPORTED, "%s: the 128x256 tile addresses at most 2 GB per operand", fn);
     const int zdim = p.transposed ? 8 : p.splits;
     dim3 grid((p.M + WS_BM - 1) / WS_BM, (p.Cout + WS_BN - 1) / WS_BN, zdim);
-    const size_t lds = (size_t)2 * 3 * (WS_BM + WS_BN) * CBK * sizeof(uint16_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_conv_split_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool one = p.max_order == 0;
+    size_t lds = (size_t)2 * (one ? 1 : 3) * (WS_BM + WS_BN) * CBK * sizeof(uint16_t);
+    const size_t cs = (size_t)64 * (WS_BN + 4) * sizeof(float);   // the epilogue's C staging
+    if (cs > lds) lds = cs;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[one]) {
+        hipError_t e = one ? hipFuncSetAttribute((const void*)k_conv_split_ws<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                           : hipFuncSetAttribute((const void*)k_conv_split_ws<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
-        attr_set = true;
+        attr_set[one] = true;
     }
-    hipLaunchKernelGGL(k_conv_split_ws, grid, dim3(512), lds, st, p, (const uint16_t*)p.w);
+    if (one) hipLaunchKernelGGL(k_conv_split_ws<true>, grid, dim3(512), lds, st, p, (const uint16_t*)p.w);
+    else hipLaunchKernelGGL(k_conv_split_ws<false>, grid, dim3(512), lds, st, p, (const uint16_t*)p.w);
     return NDET_OK;
 }
 
@@ -556,7 +598,9 @@ struct HaloRowMap {
 
 // NT16: 16x16 tiles per consumer wave along N; WGN: consumer waves along N (2 along M).  <4,2>: 128 channels, <8,2>: 256 channels with
 // one consumer wave per SIMD, <4,4>: 256 channels with two consumer waves per SIMD (each covers the other's LDS latency).
-template <int NT16, int WGN>
+// SCH 0: three bf16 planes, six products (fp32-class to 2^-24).  SCH 1: two fp16 planes, three products (see spl_split4_f16).
+// SCH 2: the leading bf16 plane only, one product (bf16 autocast arithmetic); the weights keep their three-plane layout.
+template <int NT16, int WGN, int SCH>
 __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const Conv3dParams p, const uint16_t* __restrict__ wsplit, const HaloGeom g) {
     constexpr int BN = 16 * NT16 * WGN;
     constexpr int NCONS = 2 * WGN, NTHR = 64 * (NCONS + 4);
@@ -564,11 +608,13 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
     constexpr int NSTAGE = (BN == 128) ? 3 : 2;
     constexpr int NPIECE = (HALO_MAX * 8 + 255) / 256;
     constexpr int APL = HALO_MAX * CBK, BPL = BN * CBK;   // one plane, elements
-    constexpr int BSTAGE = 3 * BPL;
+    constexpr int NPL = SCH == 1 ? 2 : (SCH == 2 ? 1 : 3);   // operand planes staged and multiplied
+    constexpr int WPL = SCH == 1 ? 2 : 3;                    // planes per K step in the weight tensor
+    constexpr int BSTAGE = NPL * BPL;
     constexpr int BR = BN / 64;                            // weight rows per producer thread and plane
-    constexpr int NB = 3 * BR;                             // LDS-DMA instructions per producer thread and K step
+    constexpr int NB = NPL * BR;                             // LDS-DMA instructions per producer thread and K step
     extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
-    uint16_t* Bs = lds16 + 3 * APL;
+    uint16_t* Bs = lds16 + NPL * APL;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -637,12 +683,12 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
         const unsigned wtile_b = (unsigned)p.Cout * CBK * 2;
         int dt = 0, dc = 0;   // tap and chunk (relative to cb) of the next weight tile to fetch
         auto dma_b = [&](int u) {   // tile u -> stage u % NSTAGE
-            const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)dt * nch_all + cb + dc) * 3) * wtile_b);
+            const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)dt * nch_all + cb + dc) * WPL) * wtile_b);
             uint16_t* stage = Bs + (u % NSTAGE) * BSTAGE;
 #pragma unroll
             for (int i = 0; i < BR; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
+                for (int pl = 0; pl < NPL; ++pl) {
                     uint16_t* dst = stage + pl * BPL + (64 * i + pw4 * 16) * CBK;   // wave-uniform; the hardware adds lane * 16 B
                     spl_dma16(bres, dst, bvoff[i], __builtin_amdgcn_readfirstlane(soff + pl * wtile_b));
                 }
@@ -662,11 +708,14 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
             for (int i = 0; i < NPIECE; ++i) {
                 const u32x4 u = ra[i];
                 uint2 s0, s1, s2;
-                spl_split4(make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)), s0, s1, s2);
+                const float4 xv = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+                if (SCH == 1) spl_split4_f16(xv, p.xscale, s0, s1);
+                else if (SCH == 2) s0 = make_uint2(spl_pack(xv.x, xv.y), spl_pack(xv.z, xv.w));
+                else spl_split4(xv, s0, s1, s2);
                 if (adst[i] != ~0u) {
                     *reinterpret_cast<uint2*>(base + adst[i]) = s0;
-                    *reinterpret_cast<uint2*>(base + adst[i] + APL * 2) = s1;
-                    *reinterpret_cast<uint2*>(base + adst[i] + APL * 4) = s2;
+                    if (NPL > 1) *reinterpret_cast<uint2*>(base + adst[i] + APL * 2) = s1;
+                    if (NPL > 2) *reinterpret_cast<uint2*>(base + adst[i] + APL * 4) = s2;
                 }
             }
         };
@@ -727,20 +776,20 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
             for (int t = 0; t < Tin; ++t, ++s) {
                 const int tapoff = (kd * g.HH + kh) * g.HW + kw;
                 const uint16_t* bst = Bs + (s % NSTAGE) * BSTAGE + boff;
-                bf16x8 fa[3][4], fb[3][NT16];
+                bf16x8 fa[NPL][4], fb[NPL][NT16];
 #pragma unroll
                 for (int ta = 0; ta < 4; ++ta) {
                     const int hr = hr0[ta] + tapoff;
                     const uint16_t* ap = lds16 + hr * CBK + ((fc ^ ws_swz(hr)) * 8);
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) fa[pl][ta] = *reinterpret_cast<const bf16x8*>(ap + pl * APL);
+                    for (int pl = 0; pl < NPL; ++pl) fa[pl][ta] = *reinterpret_cast<const bf16x8*>(ap + pl * APL);
                 }
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
                     for (int tb = 0; tb < NT16; ++tb) fb[pl][tb] = *reinterpret_cast<const bf16x8*>(bst + pl * BPL + tb * 16 * CBK);
 #pragma unroll
-                for (int order = 2; order >= 0; --order)
+                for (int order = NPL - 1; order >= 0; --order)
                     if (order <= p.max_order)
 #pragma unroll
                     for (int pa = 0; pa <= order; ++pa) {
@@ -748,8 +797,10 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
 #pragma unroll
                         for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-                            for (int tb = 0; tb < NT16; ++tb)
-                                acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pa][ta], fb[pbb][tb], acc[ta][tb], 0, 0, 0);
+                            for (int tb = 0; tb < NT16; ++tb) {
+                                if (SCH == 1) acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[pa][ta]), __builtin_bit_cast(f16x8, fb[pbb][tb]), acc[ta][tb], 0, 0, 0);
+                                else acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pa][ta], fb[pbb][tb], acc[ta][tb], 0, 0, 0);
+                            }
                     }
                 if (++kw == wkw) {
                     kw = 0;
@@ -807,8 +858,9 @@ static bool halo_geometry(const Conv3dParams& p, int halo_max, HaloGeom& g) {
     return best < 1e29;
 }
 
-template <int NT16, int WGN>
+template <int NT16, int WGN, int SCH = 0>
 static int split_launch_halo(const Conv3dParams& p, hipStream_t st, const char* fn) {
+    constexpr int NPL = SCH == 1 ? 2 : (SCH == 2 ? 1 : 3);
     constexpr int BN = 16 * NT16 * WGN, HALO_MAX = (BN == 128) ? 400 : 224, NSTAGE = (BN == 128) ? 3 : 2;
     NDET_REQUIRE(!p.transposed && p.sd == 1 && p.sh == 1 && p.sw == 1 && (p.kd & 1) && (p.kh & 1) && (p.kw & 1) && p.pd == p.kd / 2 &&
                      p.ph == p.kh / 2 && p.pw == p.kw / 2,
@@ -819,35 +871,35 @@ static int split_launch_halo(const Conv3dParams& p, hipStream_t st, const char* 
     HaloGeom g;
     NDET_REQUIRE(halo_geometry(p, HALO_MAX, g), NDET_E_UNSUPPORTED, "%s: no patch shape fits the halo tile", fn);
     dim3 grid(g.npd * g.nph * g.npw, (p.Cout + BN - 1) / BN, p.splits);
-    size_t lds = (size_t)(3 * HALO_MAX * CBK + NSTAGE * 3 * BN * CBK) * sizeof(uint16_t);
+    size_t lds = (size_t)(NPL * HALO_MAX * CBK + NSTAGE * NPL * BN * CBK) * sizeof(uint16_t);
     const size_t cs = (size_t)64 * (BN + 4) * sizeof(float);
     if (cs > lds) lds = cs;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_conv_split_halo<NT16, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_conv_split_halo<NT16, WGN, SCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv_split_halo<NT16, WGN>), grid, dim3(64 * (2 * WGN + 4)), lds, st, p, (const uint16_t*)p.w, g);
+    hipLaunchKernelGGL((k_conv_split_halo<NT16, WGN, SCH>), grid, dim3(64 * (2 * WGN + 4)), lds, st, p, (const uint16_t*)p.w, g);
     return NDET_OK;
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool ONE = false>
 static int split_launch_tile(const Conv3dParams& p, hipStream_t st, const char* fn) {
     const int zdim = p.transposed ? 8 : p.splits;
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, zdim);
-    size_t lds = (size_t)3 * (BM + BN) * SPL_RS * sizeof(uint16_t);
+    size_t lds = (size_t)(ONE ? 1 : 3) * (BM + BN) * SPL_RS * sizeof(uint16_t);
     const size_t cs = (size_t)(BM / WGM) * (BN + 4) * sizeof(float);
     if (cs > lds) lds = cs;
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_conv_split<BM, BN, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute((const void*)k_conv_split<BM, BN, WGM, WGN, ONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL((k_conv_split<BM, BN, WGM, WGN>), grid, dim3(64 * WGM * WGN), lds, st, p, (const uint16_t*)p.w);
+    hipLaunchKernelGGL((k_conv_split<BM, BN, WGM, WGN, ONE>), grid, dim3(64 * WGM * WGN), lds, st, p, (const uint16_t*)p.w);
     return NDET_OK;
 }
 
@@ -856,13 +908,16 @@ int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn)
     if (tile == 0) tile = (big_tiles >= 192 && p.Cout >= 128) ? 128 : 64;
     int rc;
     switch (tile) {
-        case 64: rc = split_launch_tile<64, 64, 2, 2>(p, st, fn); break;
-        case 128: rc = split_launch_tile<128, 128, 2, 2>(p, st, fn); break;
-        case 12864: rc = split_launch_tile<128, 64, 2, 2>(p, st, fn); break;
+        case 64: rc = p.max_order == 0 ? split_launch_tile<64, 64, 2, 2, true>(p, st, fn) : split_launch_tile<64, 64, 2, 2>(p, st, fn); break;
+        case 128: rc = p.max_order == 0 ? split_launch_tile<128, 128, 2, 2, true>(p, st, fn) : split_launch_tile<128, 128, 2, 2>(p, st, fn); break;
+        case 12864: rc = p.max_order == 0 ? split_launch_tile<128, 64, 2, 2, true>(p, st, fn) : split_launch_tile<128, 64, 2, 2>(p, st, fn); break;
         case 128256: rc = split_launch_ws(p, st, fn); break;
-        case 3128: rc = split_launch_halo<4, 2>(p, st, fn); break;
-        case 3256: rc = split_launch_halo<8, 2>(p, st, fn); break;
-        case 3257: rc = split_launch_halo<4, 4>(p, st, fn); break;
+        case 3128: rc = p.max_order == 0 ? split_launch_halo<4, 2, 2>(p, st, fn) : split_launch_halo<4, 2>(p, st, fn); break;
+        case 3256: rc = p.max_order == 0 ? split_launch_halo<8, 2, 2>(p, st, fn) : split_launch_halo<8, 2>(p, st, fn); break;
+        case 3257: rc = p.max_order == 0 ? split_launch_halo<4, 4, 2>(p, st, fn) : split_launch_halo<4, 4>(p, st, fn); break;
+        case 4128: rc = split_launch_halo<4, 2, 1>(p, st, fn); break;    // the same tiles on two fp16 planes / three products
+        case 4256: rc = split_launch_halo<8, 2, 1>(p, st, fn); break;
+        case 4257: rc = split_launch_halo<4, 4, 1>(p, st, fn); break;
         default: ndet_set_error("%s: unknown tile %d", fn, tile); return NDET_E_INVALID;
     }
     if (rc != NDET_OK) return rc;
@@ -896,6 +951,33 @@ extern "C" int ndet_split_weights_bf16x3(const float* w_packed, int taps, int Co
     NDET_REQUIRE(Cin % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
     const int64_t work = (int64_t)taps * Cout * Cin / 2;
     hipLaunchKernelGGL(k_split_weights, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_packed, taps, Cout, Cin, planes);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
+
+// packed fp32 weights (taps, Cout, Cin) x scale -> two fp16 planes tiled per K step, (taps, Cin/32, 2, Cout, 32): w*scale = hi + lo to 2^-22
+__global__ __launch_bounds__(256) void k_split_weights_f16x2(const float* __restrict__ w, int taps, int Cout, int Cin, float scale, uint16_t* __restrict__ out) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    const int64_t n = (int64_t)taps * Cout * Cin;
+    if (i >= n) return;
+    const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), tap = (int)(i / ((int64_t)Cin * Cout));
+    const float a = w[i] * scale, b = w[i + 1] * scale;
+    const uint32_t o0 = spl_pack_f16(a, b);
+    const uint32_t o1 = spl_pack_f16(a - spl_f16_lo(o0), b - spl_f16_hi(o0));
+    const int steps = Cin / CBK;
+    uint16_t* dst = out + (((int64_t)tap * steps + ci / CBK) * 2 * Cout + co) * CBK + (ci % CBK);
+    *reinterpret_cast<uint32_t*>(dst) = o0;
+    *reinterpret_cast<uint32_t*>(dst + (int64_t)Cout * CBK) = o1;
+}
+
+extern "C" int ndet_split_weights_f16x2(const float* w_packed, int taps, int Cout, int Cin, float scale, uint16_t* planes, void* stream) {
+    const char* fn = "ndet_split_weights_f16x2";
+    NDET_REQUIRE(w_packed && planes, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(taps > 0 && Cout > 0 && Cin > 0 && scale > 0.0f, NDET_E_INVALID, "%s: sizes and scale must be positive", fn);
+    NDET_REQUIRE(Cin % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
+    const int64_t work = (int64_t)taps * Cout * Cin / 2;
+    hipLaunchKernelGGL(k_split_weights_f16x2, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_packed, taps, Cout, Cin, scale,
+                       planes);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
@@ -940,7 +1022,7 @@ extern "C" int ndet_split_weights_bf16x3_torch(const float* w_torch, int taps, i
     return NDET_OK;
 }
 
-static int conv_split_entry(const char* fn, int max_order, const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin,
+static int conv_split_entry(const char* fn, int max_order, float xscale, const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin,
                             int Cout, const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
                             const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile, void* workspace,
                             void* stream);
@@ -949,7 +1031,7 @@ extern "C" int ndet_conv_ndhwc_split(const float* in, const uint16_t* w_planes, 
                                      const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
                                      const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
                                      void* workspace, void* stream) {
-    return conv_split_entry("ndet_conv_ndhwc_split", 2, in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, transposed, scale, shift, residual,
+    return conv_split_entry("ndet_conv_ndhwc_split", 2, 0.0f, in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, transposed, scale, shift, residual,
                             residual_up2, relu, splits, tile, workspace, stream);
 }
 
@@ -957,18 +1039,29 @@ extern "C" int ndet_conv_ndhwc_bf16(const float* in, const uint16_t* w_planes, f
                                     const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
                                     const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
                                     void* workspace, void* stream) {
-    return conv_split_entry("ndet_conv_ndhwc_bf16", 0, in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, transposed, scale, shift, residual,
+    return conv_split_entry("ndet_conv_ndhwc_bf16", 0, 0.0f, in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, transposed, scale, shift, residual,
                             residual_up2, relu, splits, tile, workspace, stream);
 }
 
-static int conv_split_entry(const char* fn, int max_order, const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin,
+extern "C" int ndet_conv_ndhwc_f16x2(const float* in, const uint16_t* w_planes_f16, float* out, int D, int H, int W, int Cin, int Cout,
+                                     const int* kernel, const int* stride, const int* pad, const float* scale, const float* shift,
+                                     const float* residual, int relu, int splits, int tile, float xscale, void* workspace, void* stream) {
+    const char* fn = "ndet_conv_ndhwc_f16x2";
+    NDET_REQUIRE(tile == 4128 || tile == 4256 || tile == 4257, NDET_E_INVALID, "%s: tile must be 4128, 4256 or 4257", fn);
+    NDET_REQUIRE(xscale > 0.0f, NDET_E_INVALID, "%s: xscale must be a positive power of two", fn);
+    return conv_split_entry(fn, 1, xscale, in, w_planes_f16, out, D, H, W, Cin, Cout, kernel, stride, pad, 0, scale, shift, residual, 0, relu, splits, tile,
+                            workspace, stream);
+}
+
+static int conv_split_entry(const char* fn, int max_order, float xscale, const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin,
                             int Cout, const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
                             const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile, void* workspace,
                             void* stream) {
     NDET_REQUIRE(in && w_planes && out && kernel && stride && pad, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
     NDET_REQUIRE((scale == nullptr) == (shift == nullptr), NDET_E_INVALID, "%s: scale and shift go together", fn);
-    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128 || tile == 12864 || tile == 128256 || tile == 3128 || tile == 3256 || tile == 3257), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
+    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128 || tile == 12864 || tile == 128256 || tile == 3128 || tile == 3256 || tile == 3257 ||
+                                          (xscale > 0.0f && (tile == 4128 || tile == 4256 || tile == 4257))), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
     NDET_REQUIRE(Cin % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
     NDET_REQUIRE((((uintptr_t)in | (uintptr_t)w_planes) & 15) == 0, NDET_E_UNSUPPORTED, "%s: in / weights must be 16-byte aligned", fn);
     Conv3dParams p;
@@ -976,6 +1069,7 @@ static int conv_split_entry(const char* fn, int max_order, const float* in, cons
     p.partial = (float*)workspace;
     p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
     p.max_order = max_order;
+    p.xscale = xscale;
     if (transposed) {
         for (int a = 0; a < 3; ++a)
             NDET_REQUIRE(kernel[a] == 2 && stride[a] == 2 && pad[a] == 0, NDET_E_UNSUPPORTED, "%s: transposed conv supports kernel 2 stride 2 pad 0 only", fn);
