@@ -348,8 +348,9 @@ def main():
                 return None
             avg = sum(ms) / len(ms)
             ach = abytes / (avg * 1e-3) / 1e9
+            tr = next((v for k, v in traffic.items() if k.startswith(name)), None)   # profile names carry template arguments
             return {"kernel": label, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": traffic.get(name), "traffic_source": None if traffic.get(name) is None else
+                    "traffic": tr, "traffic_source": None if tr is None else
                     f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                     "algorithmic_bytes": abytes, "avg_launch_ms": avg, "median_launch_ms": ms[len(ms) // 2], "launches": len(ms)}
 

@@ -211,3 +211,60 @@ def test_cfg5_res101_101_views_320x480_80x80x32(device):
     assert torch.equal(res["labels_3d"], same_in["labels"])
     torch.testing.assert_close(res["scores_3d"], same_in["scores"], rtol=1e-5, atol=1e-6)
     print(f"cfg5: volume err {err:.2e} (scale {scale:.2f}), {len(res['labels_3d'])} detections from {len(same_in['cand_scores'])} candidates")
+
+
+def test_cfg4_depth_supervised_train_step_losses_vs_oracle(device):
+    """BASELINE configs[3] (nerfdet_res50_2x_low_res_depth_sp, 50 sampled views -> 10 NeRF targets + 40 sources 240x320, 2 048 rays x 64
+    samples, depth supervision): the five losses of one ``forward_train`` on the GPU (HIP autograd Functions, MFMA training
+    convolutions) against the same module evaluated on the CPU with the ORACLE standing in for the HIP ops (tests/cpu_detector.py),
+    same weights, same rays, deterministic sampling; then the backward runs and every trainable group receives a finite gradient.
+    cfg3 is the same step per rank (DDP: tests/test_ddp.py) and, with ``set_arithmetic("bf16")``, in bf16: losses within 2 %."""
+    import copy
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cpu_detector import oracle_backed_cpu_ops
+    from nerfdet_amd import conv3d, rays
+    from nerfdet_amd.presets import build_nerfdet
+    from nerfdet_amd.synth import batch_to, train_scene
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.manual_seed(0)
+    det_cpu = build_nerfdet(50, depth_supervise=True)
+    with torch.no_grad():
+        det_cpu.neck.fpn_convs[0].conv.weight.mul_(1 / 30.0)
+        det_cpu.nerf_mlp.mlp.sigma_layer.output_layer.bias.fill_(1.0)
+    det_cpu.train()
+    scene = train_scene(40, (240, 320), t_views=10, n_boxes=8, seed=4)
+    det = copy.deepcopy(det_cpu).to(device).train()
+    with oracle_backed_cpu_ops() as holder, torch.no_grad():
+        holder["rng"] = np.random.RandomState(234)
+        ref = det_cpu.train_step(scene)["log_vars"]
+    orig = rays.sample_along_camera_ray
+    rays.sample_along_camera_ray = lambda *a, **k: orig(*a, **{**k, "det": True})     # the oracle stand-in samples deterministically
+    got = {}
+    try:
+        for mode in ("bf16", "bf16x3"):          # fp32-class last: its gradients are the ones inspected below
+            prev = conv3d.set_arithmetic(mode)
+            try:
+                rays.rng = np.random.RandomState(234)
+                det.zero_grad(set_to_none=True)
+                out = det.train_step(batch_to(scene, device))
+                got[mode] = out["log_vars"]
+                if mode == "bf16x3":
+                    out["loss"].backward()
+            finally:
+                conv3d.set_arithmetic(prev)
+    finally:
+        rays.sample_along_camera_ray = orig
+    keys = ("loss_centerness", "loss_bbox", "loss_cls", "loss_nvs", "loss_depth", "loss")
+    assert set(keys) <= set(ref) and all(np.isfinite(ref[k]) for k in keys)
+    for k in keys:
+        assert abs(got["bf16x3"][k] - ref[k]) <= 2e-3 * max(1.0, abs(ref[k])), (k, got["bf16x3"][k], ref[k])
+        assert abs(got["bf16"][k] - ref[k]) <= 2e-2 * max(1.0, abs(ref[k])), (k, got["bf16"][k], ref[k])
+    named = dict(det.named_parameters())
+    for name in ("backbone.layer2.0.conv1.weight", "backbone.layer4.2.conv3.weight", "neck.fpn_convs.0.conv.weight", "mapping.0.weight",
+                 "nerf_mlp.mlp.rgb_layer.output_layer.weight", "neck_3d.down_layer_0.0.conv1.weight", "neck_3d.out_block_2.0.weight",
+                 "bbox_head.cls_conv.weight", "bbox_head.reg_conv.weight"):
+        g = named[name].grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0, name
+    print("cfg4 losses (oracle-backed CPU | GPU fp32-class | GPU bf16):", {k: (round(ref[k], 5), round(got["bf16x3"][k], 5), round(got["bf16"][k], 5)) for k in keys})
