@@ -6,17 +6,21 @@
 //   mean = sum over ALL views / (cnt + 1e-8) (cnt = views seeing it in the stride-4 map; not zeroed at cnt == 0),
 //   cov  = exp(-sum over ALL views (value - mean)^2 / (cnt + 1e-8)), 0 where cnt == 0.
 // What changed is the mapping onto the machine, the same scheme as the packed ray sampler (ray_stats_kernels.hip):
-//   * a voxel occupies cm/4 lanes holding one channel QUAD each (one 16-byte load per view instead of four 4-byte ones) plus one
-//     lane for the three colour planes: 7 voxels share a wave at cm = 32 (63 of 64 lanes busy, was 35);
+//   * a lane holds one channel QUAD (one 16-byte load per view instead of four 4-byte ones), one more lane the three colour planes;
 //   * both projections of a (voxel, view) pair are evaluated once, lanes over views, and parked in LDS as element offsets;
-//   * each lane walks only the views that see the voxel in ITS map (set bits of its ballot), two per trip;
-//   * one walk: the sum for the mean and, with the first gathered value as pivot, the shifted sums for the variance
-//         sum_seen (v - mean)^2 = sum (v - c)^2 - 2 (mean - c) sum (v - c) + n_seen (mean - c)^2,   + n_unseen (fill - mean)^2.
+//   * each lane walks only views that see the voxel in ITS map (set bits of its ballot), eight gathers per trip;
+//   * one walk: the sum for the mean and the shifted sums for the variance (pivot = the fill value), see the kernel's comment.
 // Compiled with -ffp-contract=off.
 #include "ndet_common.hpp"
 
 #define DK_ROUNDS 2  // view rounds of 64 kept in registers: n_views <= 128
 
+// One voxel per wavefront.  The voxel's views are dealt round-robin to SPLIT = 64 / (cm/4 + 1) lane groups (7 at cm = 32), each group
+// the cm/4 + 1 channel-quad lanes of the scheme above: a voxel seen by all 50 views is ONE trip of eight gathers per lane instead
+// of a chain of seven, and the grid is 25 600 waves instead of 3 658 -- the launch used to last as long as its longest chain
+// (3.6 waves per SIMD, all resident at once).  The groups share the pivot (the fill value: the Linear's bias / 0), so their partial
+// sums add; they meet in LDS.  With pivot = fill the views that do not see the voxel drop out of the shifted sums:
+//     sum_all (v - mean)^2 = sum_seen (v - fill)^2 - 2 (mean - fill) sum_seen (v - fill) + n_views (mean - fill)^2.
 template <int DUMMY>
 __global__ __launch_bounds__(256) void k_density_features_packed(const float* __restrict__ mapped, int n_views, int cm, int h, int w,
                                                                  int mview_pitch, int mrow_pitch, const float* __restrict__ bias,
@@ -27,20 +31,20 @@ __global__ __launch_bounds__(256) void k_density_features_packed(const float* __
     extern __shared__ int2 s_off[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lps = (cm >> 2) + 1;
-    const int G = 64 / lps;
-    const int g = lane / lps, sub = lane - g * lps;
+    const int SPLIT = 64 / lps;
+    const int grp = lane / lps, sub = lane - grp * lps;
     const int blk = ndet_xcd_remap(blockIdx.x, n_blocks);      // neighbouring voxel blocks hit the same pixels: keep them on one XCD's L2
-    const int n_base = (blk * 4 + wave) * G;
-    int2* rec = s_off + (size_t)wave * G * nvp;
+    const int n = blk * 4 + wave;                              // this wave's voxel
+    int2* rec = s_off + (size_t)wave * nvp;
+    float4* part = reinterpret_cast<float4*>(s_off + (size_t)4 * nvp) + (size_t)wave * 64 * 3;   // [lane][acc, q, s1]
     const int rounds = (n_views + 63) >> 6;
+    const bool live = n < N;
 
     // ---- phase 1: lanes over views, both projections of every (voxel, view) pair once ----
-    unsigned long long my_f[DK_ROUNDS], my_r[DK_ROUNDS];
+    unsigned long long mf[DK_ROUNDS], mr[DK_ROUNDS];
 #pragma unroll
-    for (int r = 0; r < DK_ROUNDS; ++r) { my_f[r] = 0ull; my_r[r] = 0ull; }
-    for (int gg = 0; gg < G; ++gg) {
-        const int n = n_base + gg;
-        if (n >= N) break;   // wave-uniform
+    for (int r = 0; r < DK_ROUNDS; ++r) { mf[r] = 0ull; mr[r] = 0ull; }
+    if (live) {
         const float px = points[n], py = points[N + n], pz = points[2 * N + n];
 #pragma unroll
         for (int r = 0; r < DK_ROUNDS; ++r) {
@@ -51,34 +55,25 @@ __global__ __launch_bounds__(256) void k_density_features_packed(const float* __
                     int xf, yf, xr, yr;
                     okf = ndet_project(proj + v * 12, px, py, pz, w, h, xf, yf);
                     okr = ndet_project(rgb_proj + v * 12, px, py, pz, W, H, xr, yr);
-                    rec[gg * nvp + v] = make_int2(v * mview_pitch + yf * mrow_pitch + xf * cm, v * rsv + yr * rsy + xr);
+                    rec[v] = make_int2(v * mview_pitch + yf * mrow_pitch + xf * cm, v * rsv + yr * rsy + xr);
                 }
-                const unsigned long long bf = __ballot(okf), br = __ballot(okr);
-                if (g == gg) { my_f[r] = bf; my_r[r] = br; }
+                mf[r] = __ballot(okf);
+                mr[r] = __ballot(okr);
             }
         }
     }
     __syncthreads();
 
-    // ---- phase 2: lanes over (voxel, channel quad) ----
-    const int my_n = n_base + g;
-    const bool on = g < G && my_n < N;
+    // ---- phase 2: lanes over (view group, channel quad) ----
+    const bool on = live && grp < SPLIT;
     const bool is_rgb = sub == 0;
     const int fq = sub - 1;
     float4 fill = make_float4(0.f, 0.f, 0.f, 0.f);            // what a view that does not see the voxel contributes (nerfdet.py:233)
     if (!is_rgb && on) fill = *reinterpret_cast<const float4*>(bias + 4 * fq);
     const float* fbase = mapped + 4 * max(fq, 0);
-    int cnt = 0, n_mine = 0;
-#pragma unroll
-    for (int r = 0; r < DK_ROUNDS; ++r) {
-        cnt += __popcll(my_f[r]);
-        n_mine += __popcll(is_rgb ? my_r[r] : my_f[r]);
-    }
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), q = acc, s1 = acc, piv = acc;
-    bool have = false;
-    const int2* myrec = rec + (on ? g : 0) * nvp;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), q = acc, s1 = acc;
     auto fetch = [&](int idx) -> float4 {
-        const int2 o = myrec[idx];
+        const int2 o = rec[idx];
         if (is_rgb) {
             const float* p = rgb + o.y;
             return make_float4(p[0], p[rsc], p[2 * rsc], 0.0f);
@@ -87,18 +82,18 @@ __global__ __launch_bounds__(256) void k_density_features_packed(const float* __
     };
     auto take = [&](const float4& v) {
         acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
-        if (!have) { piv = v; have = true; }
-        const float dx = v.x - piv.x, dy = v.y - piv.y, dz = v.z - piv.z, dw = v.w - piv.w;
+        const float dx = v.x - fill.x, dy = v.y - fill.y, dz = v.z - fill.z, dw = v.w - fill.w;
         q.x = q.x + dx * dx; q.y = q.y + dy * dy; q.z = q.z + dz * dz; q.w = q.w + dw * dw;
         s1.x = s1.x + dx; s1.y = s1.y + dy; s1.z = s1.z + dz; s1.w = s1.w + dw;
     };
+    // the views of group g: bits g, g + SPLIT, g + 2 SPLIT, ... of the round's mask
+    unsigned long long stripe = 0ull;
+    for (int b = grp; b < 64; b += SPLIT) stripe |= 1ull << b;
 #pragma unroll
     for (int r = 0; r < DK_ROUNDS; ++r) {
         if (r >= rounds) break;
-        unsigned long long m = on ? (is_rgb ? my_r[r] : my_f[r]) : 0ull;
+        unsigned long long m = on ? ((is_rgb ? mr[r] : mf[r]) & stripe) : 0ull;
         while (__ballot(m != 0ull) != 0ull) {
-            // eight views per trip: eight independent 16-byte gathers in flight per lane (the kernel is latency bound: a wave's chain
-            // of trips is what the launch waits for)
             bool hh[8];
             int bb[8];
 #pragma unroll
@@ -118,28 +113,43 @@ __global__ __launch_bounds__(256) void k_density_features_packed(const float* __
                 if (hh[k]) take(vv[k]);
         }
     }
-    if (!on) return;
+    // ---- the groups' partial sums meet in LDS; group 0 finishes the voxel ----
+    part[lane * 3 + 0] = acc;
+    part[lane * 3 + 1] = q;
+    part[lane * 3 + 2] = s1;
+    __syncthreads();
+    if (!(on && grp == 0)) return;
+    for (int g2 = 1; g2 < SPLIT; ++g2) {
+        const float4 a2 = part[(g2 * lps + sub) * 3 + 0], q2 = part[(g2 * lps + sub) * 3 + 1], s2 = part[(g2 * lps + sub) * 3 + 2];
+        acc.x += a2.x; acc.y += a2.y; acc.z += a2.z; acc.w += a2.w;
+        q.x += q2.x; q.y += q2.y; q.z += q2.z; q.w += q2.w;
+        s1.x += s2.x; s1.y += s2.y; s1.z += s2.z; s1.w += s2.w;
+    }
+    int cnt = 0, n_mine = 0;
+#pragma unroll
+    for (int r = 0; r < DK_ROUNDS; ++r) {
+        cnt += __popcll(mf[r]);
+        n_mine += __popcll(is_rgb ? mr[r] : mf[r]);
+    }
     const float denom = (float)cnt + 1e-8f;
-    const float ns = (float)n_mine, nu = (float)(n_views - n_mine);
-    auto finish = [&](float a, float qq, float ss, float pv, float fl, float& mean, float& cov) {
+    const float nu = (float)(n_views - n_mine), nv = (float)n_views;
+    auto finish = [&](float a, float qq, float ss, float fl, float& mean, float& cov) {
         const float sum = a + nu * fl;
         mean = sum / denom;                                   // NOT zeroed at cnt == 0 (nerfdet.py:241)
-        const float dm = mean - pv;
-        float s = qq - 2.0f * dm * ss + ns * (dm * dm);
-        s = fmaxf(s, 0.0f);
-        const float df = fl - mean;
-        s = s + nu * (df * df);
+        const float dm = mean - fl;
+        float s = qq - 2.0f * dm * ss + nv * (dm * dm);
+        s = fmaxf(s, 0.0f);                                   // a sum of squares: rounding may leave -1 ulp
         float var = s / denom;
         if (cnt == 0) var = 1e6f;                             // nerfdet.py:249
         cov = expf(-var);
     };
     float4 mean, cov;
-    finish(acc.x, q.x, s1.x, piv.x, fill.x, mean.x, cov.x);
-    finish(acc.y, q.y, s1.y, piv.y, fill.y, mean.y, cov.y);
-    finish(acc.z, q.z, s1.z, piv.z, fill.z, mean.z, cov.z);
-    finish(acc.w, q.w, s1.w, piv.w, fill.w, mean.w, cov.w);
+    finish(acc.x, q.x, s1.x, fill.x, mean.x, cov.x);
+    finish(acc.y, q.y, s1.y, fill.y, mean.y, cov.y);
+    finish(acc.z, q.z, s1.z, fill.z, mean.z, cov.z);
+    finish(acc.w, q.w, s1.w, fill.w, mean.w, cov.w);
     const int F = 2 * (3 + cm);
-    float* row = out + (int64_t)my_n * F + (is_rgb ? 0 : 2 * (3 + 4 * fq));   // interleaved [mean_c, cov_c] (nerfdet.py:251-253)
+    float* row = out + (int64_t)n * F + (is_rgb ? 0 : 2 * (3 + 4 * fq));   // interleaved [mean_c, cov_c] (nerfdet.py:251-253)
     *reinterpret_cast<float2*>(row + 0) = make_float2(mean.x, cov.x);
     *reinterpret_cast<float2*>(row + 2) = make_float2(mean.y, cov.y);
     *reinterpret_cast<float2*>(row + 4) = make_float2(mean.z, cov.z);
@@ -162,11 +172,9 @@ extern "C" int ndet_density_features_packed(const float* mapped_nhwc, int n_view
     NDET_REQUIRE(mview_pitch % 4 == 0 && mrow_pitch % 4 == 0 && (((uintptr_t)mapped_nhwc | (uintptr_t)bias) & 15) == 0, NDET_E_UNSUPPORTED,
                  "%s: mapped features / bias must keep channel quads 16-byte aligned", fn);
     NDET_REQUIRE(((uintptr_t)global_feat & 7) == 0, NDET_E_UNSUPPORTED, "%s: global_feat must be 8-byte aligned", fn);
-    const int lps = cm / 4 + 1, G = 64 / lps;
     const int nvp = ((n_views + 63) / 64) * 64;
-    const int lds = 4 * G * nvp * (int)sizeof(int2);
-    NDET_REQUIRE(lds <= 64 * 1024, NDET_E_UNSUPPORTED, "%s: %d bytes of LDS needed (cm too small for this many views)", fn, lds);
-    const int64_t blocks = ((int64_t)N + 4 * G - 1) / (4 * G);
+    const int lds = 4 * nvp * (int)sizeof(int2) + 4 * 64 * 3 * (int)sizeof(float4);
+    const int64_t blocks = ((int64_t)N + 3) / 4;               // one voxel per wavefront
     NDET_REQUIRE(blocks < ((int64_t)1 << 31), NDET_E_UNSUPPORTED, "%s: too many voxels", fn);
     hipLaunchKernelGGL(k_density_features_packed<0>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, mapped_nhwc, n_views, cm, h, w,
                        (int)mview_pitch, (int)mrow_pitch, bias, rgb, H, W, (int)rsv, (int)rsc, (int)rsy, points, N, projection, rgb_projection,

@@ -190,7 +190,7 @@ def backproject_aggregate(features: Tensor, points: Tensor, projection: Tensor, 
 # --------------------------------------------------------------------------------------------
 def density_packed_ok(n_views: int, cm: int, mapped: Optional[Tensor] = None, bias: Optional[Tensor] = None) -> bool:
     """Shapes the packed K2 kernel (csrc/density_kernels.hip) takes; everything else runs on the generic kernel."""
-    if cm % 4 or cm > 128 or n_views > 128 or 4 * (64 // (cm // 4 + 1)) * ((n_views + 63) // 64 * 64) * 8 > 64 * 1024:
+    if cm % 4 or cm > 128 or n_views > 128:
         return False
     if mapped is not None and (mapped.stride(0) % 4 or mapped.stride(2) % 4 or mapped.data_ptr() % 16):
         return False
