@@ -249,6 +249,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // world)))   # N ranks share the host: do not oversubscribe it while building
 
     import nerfdet_amd.conv3d as C3
     from nerfdet_amd import trace

@@ -15,7 +15,7 @@ from torch import nn
 
 from . import _lib, trace
 from ._lib import check
-from .conv_tuning import TUNED, TUNED_SPLIT
+from .conv_tuning import TUNED, TUNED_BF16, TUNED_SPLIT
 
 # Arithmetic of the convolution kernels: "bf16x3" = fp32 operands split exactly into three bf16 terms, six bf16-MFMA
 # products accumulated in fp32 (csrc/conv_split_kernels.hip; fp32-level error, 16x the MFMA rate per product);
@@ -78,7 +78,8 @@ def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: 
     """Tile (64 = 64x64, 128 = 128x128, 12864 = 128 rows x 64 channels, 128256 = wave-specialised 128 rows x 256 channels, 3128 / 3256 = halo-stationary 128-voxel patch x 128 / 256 channels)
     and split-K factor for the bf16x3 kernel."""
     if tile == 0 and splits == 0:
-        hit = TUNED_SPLIT.get((m, cout, k_iters, int(transposed)))
+        key = (m, cout, k_iters, int(transposed))
+        hit = (TUNED_BF16.get(key) if ARITHMETIC == "bf16" else None) or TUNED_SPLIT.get(key)
         if hit is not None:
             return hit
     if tile == 0:   # shapes outside the measured table: the pattern the sweeps showed

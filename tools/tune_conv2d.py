@@ -26,7 +26,7 @@ def main():
     from nerfdet_amd import conv3d as C3
     if len(sys.argv) > 1:
         C3.set_arithmetic(sys.argv[1])
-    tiles = (64, 128, 12864, 128256, 3128, 3256, 3257) if C3.ARITHMETIC == "bf16x3" else (64, 128)
+    tiles = (64, 128, 12864, 128256, 3128, 3256, 3257) if C3.ARITHMETIC in ("bf16x3", "bf16") else (64, 128)
     print("arithmetic", C3.ARITHMETIC, flush=True)
     dev = torch.device("cuda")
     tot_best = tot_auto = 0.0
