@@ -142,9 +142,26 @@ int ndet_select_candidates(int n_levels, const float* const* best, const int64_t
                            const int* n, float score_thr, float* out_best, int64_t* out_label, float* out_boxes, int* counts,
                            void* stream);
 
+/* The same compaction with the per-level top-``nms_pre`` cut of dense_heads/imvoxel_head_v2.py:272-276 decided on the device (radix
+ * select over the score bits): the kept set per level is what ``topk(nms_pre)`` followed by ``scores > score_thr`` keeps.
+ * counts (n_levels + 2 ints): per level after the cut, total, survivors before the cut. */
+int ndet_select_candidates_topk(int n_levels, const float* const* best, const int64_t* const* label, const float* const* boxes,
+                                const int* n, float score_thr, int nms_pre, float* out_best, int64_t* out_label, float* out_boxes,
+                                int* counts, void* stream);
+
 /* picked candidates -> detections in pick order: (centre, size) boxes, scores, labels (imvoxel_head_v2.py:546-555). */
 int ndet_gather_detections(const int64_t* keep, int n_keep, const float* boxes, const float* scores, const int64_t* labels,
                            float* out_boxes, float* out_scores, int64_t* out_labels, void* stream);
+
+/* The tail of get_bboxes without a host round trip (dense_heads/imvoxel_head_v2.py:216-285,528-555 + core/bbox/transforms.py:49-67):
+ * greedy NMS (core/post_processing/box3d_nms.py:91-138) over the candidates ndet_select_candidates compacted -- their count is read
+ * on the device from counts[n_levels] -- and the picks packed for ONE device-to-host copy: out_packed = {n_keep, n_candidates,
+ * status, 0} followed by up to k_cap rows [x, y, z_bottom, dx, dy, dz, 0, score, label].  status != 0 (more than n_cap <= 4096
+ * candidates, a level with more than nms_pre survivors, more picks than rows): the caller repeats the scene on the synchronous
+ * path.  workspace: ndet_nms_workspace_bytes(n_cap). */
+int ndet_nms_pack_detections(const float* cand_boxes, const float* cand_scores, const int64_t* cand_labels, const int* counts,
+                             int n_levels, int nms_pre, int n_cap, float thresh, int64_t* keep, int64_t* n_keep, void* workspace,
+                             float* out_packed, int k_cap, void* stream);
 
 /* A9. Samples along rays. Replaces sample_along_camera_ray(), mmdet3d/models/model_utils/render_ray.py:145-189
  * (inv_uniform=False).  ray_o, ray_d (R,3); t_rand NULL (det=True) or (R,S) uniforms in [0,1) -- the stream the

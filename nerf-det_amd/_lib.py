@@ -59,7 +59,9 @@ SIGNATURES = {
     "ndet_conv_ndhwc_bf16": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_level_valid": ([_P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_select_candidates": ([c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P], c_int),
+    "ndet_select_candidates_topk": ([c_int, _P, _P, _P, _P, c_float, c_int, _P, _P, _P, _P, _P], c_int),
     "ndet_gather_detections": ([_P, c_int, _P, _P, _P, _P, _P, _P, _P], c_int),
+    "ndet_nms_pack_detections": ([_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, c_int, _P], c_int),
     "ndet_normalize_views": ([_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P], c_int),
     "ndet_target_rays": ([_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
     "ndet_wgrad_rows": ([_P] + [c_int] * 14 + [_P, _P], c_int),

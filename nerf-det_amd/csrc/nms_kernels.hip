@@ -13,9 +13,19 @@
 
 #define NMS_MAX 4096
 
-__global__ __launch_bounds__(1024) void k_nms_sort(const float* __restrict__ scores, int n, int* __restrict__ order) {
+// n_dev != null: the candidate count lives on the device (no host round trip between the compaction and the NMS); more than n_cap
+// candidates make every kernel of the chain do nothing and the packed header report it (the host then takes the synchronous path).
+__device__ __forceinline__ int nms_count(int n, const int* __restrict__ n_dev, int n_cap) {
+    if (n_dev == nullptr) return n;
+    const int m = *n_dev;
+    return m > n_cap ? 0 : m;
+}
+
+__global__ __launch_bounds__(1024) void k_nms_sort(const float* __restrict__ scores, int n, int* __restrict__ order, const int* __restrict__ n_dev,
+                                                   int n_cap) {
     __shared__ float key[NMS_MAX];
     __shared__ int idx[NMS_MAX];
+    n = nms_count(n, n_dev, n_cap);
     int m = 1;
     while (m < n) m <<= 1;
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
@@ -50,11 +60,12 @@ __device__ __forceinline__ float box_volume(const float* b) { return (b[3] - b[0
 
 __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, const int64_t* __restrict__ classes,
                                                  const int* __restrict__ order, int n, float thresh,
-                                                 unsigned long long* __restrict__ mask) {
+                                                 unsigned long long* __restrict__ mask, const int* __restrict__ n_dev, int n_cap) {
     // block (bx, by): rows 64*by.., columns 64*bx.. of the sorted list
+    n = nms_count(n, n_dev, n_cap);
     const int words = (n + 63) / 64;
     const int rb = blockIdx.y, cb = blockIdx.x;
-    if (cb < rb) return;  // only j > i matters
+    if (cb < rb || cb >= words) return;  // only j > i matters; the grid is sized for n_cap
     __shared__ float cbox[64][6];
     __shared__ long long ccls[64];
     const int cj = cb * 64 + threadIdx.x;
@@ -101,8 +112,10 @@ __device__ __forceinline__ unsigned long long nms_readlane64(unsigned long long 
 }
 
 __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long* __restrict__ mask, const int* __restrict__ order,
-                                                  int n, int64_t* __restrict__ keep, int64_t* __restrict__ n_keep) {
+                                                  int n, int64_t* __restrict__ keep, int64_t* __restrict__ n_keep, const int* __restrict__ n_dev,
+                                                  int n_cap) {
     const int lane = threadIdx.x;
+    n = nms_count(n, n_dev, n_cap);
     const int words = (n + 63) / 64;  // <= 64
     unsigned long long removed = 0ull;  // lane w holds bits [64w, 64w+64)
     int kept = 0;
@@ -171,9 +184,59 @@ extern "C" int ndet_aligned_3d_nms(const float* boxes, const float* scores, cons
     const int words = (n + 63) / 64;
     unsigned long long* mask = (unsigned long long*)workspace;
     int* order = (int*)((char*)workspace + (size_t)n * words * 8);
-    hipLaunchKernelGGL(k_nms_sort, dim3(1), dim3(1024), 0, st, scores, n, order);
-    hipLaunchKernelGGL(k_nms_mask, dim3(words, words), dim3(64), 0, st, boxes, classes, order, n, thresh, mask);
-    hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, st, mask, order, n, keep, n_keep);
+    hipLaunchKernelGGL(k_nms_sort, dim3(1), dim3(1024), 0, st, scores, n, order, (const int*)nullptr, 0);
+    hipLaunchKernelGGL(k_nms_mask, dim3(words, words), dim3(64), 0, st, boxes, classes, order, n, thresh, mask, (const int*)nullptr, 0);
+    hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, st, mask, order, n, keep, n_keep, (const int*)nullptr, 0);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
+
+// picked candidates -> one host-bound buffer: header {n_keep, n_candidates, status, 0} + rows [x, y, z_bottom, dx, dy, dz, yaw = 0, score, label]
+// (the DepthInstance3DBoxes layout of imvoxel_head_v2.py:546-555 + the bbox3d2result triple).  status bit 0: more candidates than n_cap;
+// bit 1: a level holds more than nms_pre survivors (its top-k cut would apply); bit 2: more picks than rows.
+__global__ __launch_bounds__(256) void k_pack_detections(const int64_t* __restrict__ keep, const int64_t* __restrict__ n_keep,
+                                                         const int* __restrict__ counts, int n_levels, int nms_pre, int n_cap, int k_cap,
+                                                         const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                         const int64_t* __restrict__ labels, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = counts[n_levels];
+    const int k = n > n_cap ? 0 : (int)*n_keep;
+    if (i == 0) {
+        int status = n > n_cap ? 1 : 0;
+        if (nms_pre > 0)
+            for (int l = 0; l < n_levels; ++l)
+                if (counts[l] > nms_pre) status |= 2;
+        if (k > k_cap) status |= 4;
+        out[0] = (float)k; out[1] = (float)n; out[2] = (float)status; out[3] = 0.0f;
+    }
+    if (i >= k || i >= k_cap) return;
+    const int64_t c = keep[i];
+    const float* b = boxes + c * 6;
+    float* o = out + 4 + (int64_t)i * 9;
+    const float dz = b[5] - b[2];
+    o[0] = (b[0] + b[3]) / 2.0f; o[1] = (b[1] + b[4]) / 2.0f;
+    o[2] = (b[2] + b[5]) / 2.0f + dz * -0.5f;          // gravity centre -> bottom centre, as the box container re-bases it
+    o[3] = b[3] - b[0]; o[4] = b[4] - b[1]; o[5] = dz; o[6] = 0.0f;
+    o[7] = scores[c];
+    o[8] = (float)labels[c];
+}
+
+extern "C" int ndet_nms_pack_detections(const float* cand_boxes, const float* cand_scores, const int64_t* cand_labels, const int* counts,
+                                        int n_levels, int nms_pre, int n_cap, float thresh, int64_t* keep, int64_t* n_keep, void* workspace,
+                                        float* out_packed, int k_cap, void* stream) {
+    const char* fn = "ndet_nms_pack_detections";
+    NDET_REQUIRE(cand_boxes && cand_scores && cand_labels && counts && keep && n_keep && workspace && out_packed, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(n_levels >= 1 && n_levels <= 4 && n_cap >= 1 && n_cap <= NMS_MAX && k_cap >= 1, NDET_E_INVALID, "%s: bad sizes", fn);
+    hipStream_t st = (hipStream_t)stream;
+    const int words = (n_cap + 63) / 64;
+    unsigned long long* mask = (unsigned long long*)workspace;
+    int* order = (int*)((char*)workspace + (size_t)n_cap * words * 8);
+    const int* n_dev = counts + n_levels;
+    hipLaunchKernelGGL(k_nms_sort, dim3(1), dim3(1024), 0, st, cand_scores, 0, order, n_dev, n_cap);
+    hipLaunchKernelGGL(k_nms_mask, dim3(words, words), dim3(64), 0, st, cand_boxes, cand_labels, order, 0, thresh, mask, n_dev, n_cap);
+    hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, st, mask, order, 0, keep, n_keep, n_dev, n_cap);
+    hipLaunchKernelGGL(k_pack_detections, dim3((k_cap + 255) / 256), dim3(256), 0, st, keep, n_keep, counts, n_levels, nms_pre, n_cap, k_cap, cand_boxes,
+                       cand_scores, cand_labels, out_packed);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
@@ -315,6 +378,145 @@ __global__ __launch_bounds__(1024) void k_select_candidates(const SelectLevels l
         if (tid == 0) counts[l] = base_s - level_base;
     }
     if (tid == 0) counts[lv.n_levels] = base_s;
+}
+
+// The same compaction with the per-level ``topk(nms_pre)`` cut of imvoxel_head_v2.py:272-276 decided ON THE DEVICE: when more than
+// nms_pre voxels of a level clear the threshold, the nms_pre-th largest score is found by a 3-round radix select over the float
+// bits (11 + 11 + 10 bits, a 2048-bin LDS histogram per round; positive floats order like their bit patterns) and only scores
+// above it -- plus as many equal to it as are needed, first in voxel order -- are kept.  The kept SET is the reference's
+// (its order inside a level differs: voxel order here, descending score there; the NMS sorts by score anyway).
+// counts[l] = candidates of level l after the cut, counts[n_levels] = total, counts[n_levels + 1] = survivors before any cut.
+__global__ __launch_bounds__(1024) void k_select_candidates_topk(const SelectLevels lv, float thr, int nms_pre, float* __restrict__ o_best,
+                                                                 int64_t* __restrict__ o_label, float* __restrict__ o_boxes, int* __restrict__ counts) {
+    __shared__ int wave_cnt[16], wave_eq[16];
+    __shared__ int base_s, eq_s, raw_s, sel_need;
+    __shared__ unsigned sel_prefix;
+    __shared__ int hist[2048];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { base_s = 0; raw_s = 0; }
+    __syncthreads();
+    for (int l = 0; l < lv.n_levels; ++l) {
+        const int n_l = lv.n[l];
+        const float* __restrict__ best = lv.best[l];
+        // ---- survivors of the threshold ----
+        int c = 0;
+        for (int i = tid; i < n_l; i += 1024) c += best[i] > thr ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+        if (lane == 0) wave_cnt[wave] = c;
+        __syncthreads();
+        c = 0;
+        for (int w2 = 0; w2 < 16; ++w2) c += wave_cnt[w2];
+        __syncthreads();
+        // ---- the nms_pre-th largest key, if the cut applies ----
+        unsigned K = 0u;      // keep keys > K ...
+        int ties_need = 0;    // ... and the first ties_need keys == K
+        if (nms_pre > 0 && c > nms_pre) {
+            unsigned prefix = 0u;
+            int need = nms_pre, bits_done = 0;
+            for (int r = 0; r < 3; ++r) {
+                const int width = r < 2 ? 11 : 10, shift = 32 - bits_done - width;
+                for (int b = tid; b < 2048; b += 1024) hist[b] = 0;
+                __syncthreads();
+                for (int i = tid; i < n_l; i += 1024) {
+                    const float v = best[i];
+                    if (v > thr) {
+                        const unsigned key = __float_as_uint(v);
+                        if (bits_done == 0 || (key >> (32 - bits_done)) == prefix) atomicAdd(&hist[(key >> shift) & ((1u << width) - 1u)], 1);
+                    }
+                }
+                __syncthreads();
+                if (wave == 0) {   // from the top bin down: the bin where the count of larger keys crosses `need`
+                    const int per = (1 << width) / 64;
+                    int chunk = 0;
+                    for (int b = 0; b < per; ++b) chunk += hist[lane * per + b];
+                    int suf = chunk;   // sum over lanes >= this one
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int t = __shfl_down(suf, off);
+                        if (lane + off < 64) suf += t;
+                    }
+                    const unsigned long long ok = __ballot(suf >= need);
+                    const int L = 63 - __builtin_clzll(ok);
+                    if (lane == L) {
+                        int cum = suf - chunk, bin = lane * per;
+                        for (int b = per - 1; b >= 0; --b) {
+                            const int hb = hist[lane * per + b];
+                            if (cum + hb >= need) { bin = lane * per + b; break; }
+                            cum += hb;
+                        }
+                        sel_prefix = (prefix << width) | (unsigned)bin;
+                        sel_need = need - cum;
+                    }
+                }
+                __syncthreads();
+                prefix = sel_prefix;
+                need = sel_need;
+                bits_done += width;
+                __syncthreads();
+            }
+            K = prefix;
+            ties_need = need;
+        }
+        // ---- ordered compaction ----
+        const int level_base = base_s;
+        if (tid == 0) { eq_s = 0; raw_s += c; }
+        __syncthreads();
+        for (int i0 = 0; i0 < n_l; i0 += 1024) {
+            const int i = i0 + tid;
+            const float v = i < n_l ? best[i] : 0.0f;
+            const unsigned key = __float_as_uint(v);
+            const bool surv = i < n_l && v > thr;
+            const bool eq = surv && K != 0u && key == K;
+            const unsigned long long m_eq = __ballot(eq);
+            if (lane == 0) wave_eq[wave] = __popcll(m_eq);
+            __syncthreads();
+            int eq_before = eq_s + __popcll(m_eq & ((1ull << lane) - 1ull));
+            for (int w2 = 0; w2 < wave; ++w2) eq_before += wave_eq[w2];
+            const bool keep = surv && (key > K || (eq && eq_before < ties_need));
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) wave_cnt[wave] = __popcll(m);
+            __syncthreads();
+            int off = base_s;
+            for (int w2 = 0; w2 < wave; ++w2) off += wave_cnt[w2];
+            if (keep) {
+                const int o = off + __popcll(m & ((1ull << lane) - 1ull));
+                o_best[o] = v;
+                o_label[o] = lv.label[l][i];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o_boxes[(int64_t)o * 6 + k] = lv.boxes[l][(int64_t)i * 6 + k];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int t = 0, e = 0;
+                for (int w2 = 0; w2 < 16; ++w2) { t += wave_cnt[w2]; e += wave_eq[w2]; }
+                base_s += t;
+                eq_s += e;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) counts[l] = base_s - level_base;
+    }
+    if (tid == 0) { counts[lv.n_levels] = base_s; counts[lv.n_levels + 1] = raw_s; }
+}
+
+extern "C" int ndet_select_candidates_topk(int n_levels, const float* const* best, const int64_t* const* label, const float* const* boxes,
+                                           const int* n, float score_thr, int nms_pre, float* out_best, int64_t* out_label, float* out_boxes,
+                                           int* counts, void* stream) {
+    const char* fn = "ndet_select_candidates_topk";
+    NDET_REQUIRE(best && label && boxes && n && out_best && out_label && out_boxes && counts, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(n_levels >= 1 && n_levels <= 4, NDET_E_UNSUPPORTED, "%s: 1..4 levels", fn);
+    NDET_REQUIRE(score_thr >= 0.0f, NDET_E_UNSUPPORTED, "%s: the radix select orders positive scores by their bit patterns: score_thr must be >= 0", fn);
+    SelectLevels lv;
+    lv.n_levels = n_levels;
+    for (int l = 0; l < n_levels; ++l) {
+        NDET_REQUIRE(best[l] && label[l] && boxes[l] && n[l] > 0, NDET_E_INVALID, "%s: level %d: null pointer / empty", fn, l);
+        lv.best[l] = best[l]; lv.label[l] = label[l]; lv.boxes[l] = boxes[l]; lv.n[l] = n[l];
+    }
+    hipLaunchKernelGGL(k_select_candidates_topk, dim3(1), dim3(1024), 0, (hipStream_t)stream, lv, score_thr, nms_pre, out_best, out_label, out_boxes,
+                       counts);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
 }
 
 extern "C" int ndet_select_candidates(int n_levels, const float* const* best, const int64_t* const* label, const float* const* boxes,

@@ -202,8 +202,35 @@ class ScanNetImVoxelHeadV2(nn.Module):
             c_best = torch.empty((tot,), dtype=torch.float32, device=dev)
             c_lab = torch.empty((tot,), dtype=torch.int64, device=dev)
             c_box = torch.empty((tot, 6), dtype=torch.float32, device=dev)
-            counts = torch.empty((nl + 1,), dtype=torch.int32, device=dev)
             pa = lambda ts: (ctypes.c_void_p * nl)(*[t.data_ptr() for t in ts])
+            counts = torch.empty((nl + 2,), dtype=torch.int32, device=dev)
+            # ---- fast tail: the per-level top-nms_pre cut, the NMS (candidate count read on the device) and the packing of the picks for
+            # ONE device-to-host copy, all enqueued behind the neck's kernels: no host round trip inside the post-processing ----
+            from .boxes import DepthInstance3DBoxes
+            if meta["box_type_3d"] is DepthInstance3DBoxes and float(self.test_cfg.score_thr) >= 0:
+                check(lib.ndet_select_candidates_topk(nl, pa(bests), pa(labels), pa(boxes), (ctypes.c_int * nl)(*sizes), float(self.test_cfg.score_thr),
+                                                      int(self.test_cfg.nms_pre), c_void_p(c_best.data_ptr()), c_void_p(c_lab.data_ptr()),
+                                                      c_void_p(c_box.data_ptr()), c_void_p(counts.data_ptr()), st), "select_candidates_topk")
+                n_cap, k_cap = min(tot, 4096), 1024
+                bufs = self.__dict__.setdefault("_ndet_post", {})
+                key = (str(dev), n_cap)
+                if key not in bufs:
+                    bufs[key] = (torch.empty((n_cap,), dtype=torch.int64, device=dev), torch.empty((1,), dtype=torch.int64, device=dev),
+                                 torch.empty((max(int(lib.ndet_nms_workspace_bytes(n_cap)), 8),), dtype=torch.uint8, device=dev))
+                keep, n_keep, ws = bufs[key]
+                packed_out = torch.empty((4 + k_cap * 9,), dtype=torch.float32, device=dev)
+                check(lib.ndet_nms_pack_detections(c_void_p(c_box.data_ptr()), c_void_p(c_best.data_ptr()), c_void_p(c_lab.data_ptr()),
+                                                   c_void_p(counts.data_ptr()), nl, int(self.test_cfg.nms_pre), n_cap, float(self.test_cfg.iou_thr),
+                                                   c_void_p(keep.data_ptr()), c_void_p(n_keep.data_ptr()), c_void_p(ws.data_ptr()),
+                                                   c_void_p(packed_out.data_ptr()), k_cap, st), "nms_pack_detections")
+                host = packed_out.cpu()                                   # the one host sync of the scene
+                k, status = int(host[0]), int(host[2])
+                if status == 0:
+                    rows = host[4:4 + k * 9].view(k, 9)
+                    b = object.__new__(DepthInstance3DBoxes)
+                    b.tensor, b.box_dim, b.with_yaw = rows[:, :7].contiguous(), 7, False
+                    return [(b, rows[:, 7].contiguous(), rows[:, 8].to(torch.int64))]
+            # ---- general tail (more than 4096 candidates or 1024 picks, another box container): host-driven ----
             check(lib.ndet_select_candidates(nl, pa(bests), pa(labels), pa(boxes), (ctypes.c_int * nl)(*sizes), float(self.test_cfg.score_thr),
                                              c_void_p(c_best.data_ptr()), c_void_p(c_lab.data_ptr()), c_void_p(c_box.data_ptr()),
                                              c_void_p(counts.data_ptr()), st), "select_candidates")
