@@ -21,39 +21,79 @@ __device__ __forceinline__ int nms_count(int n, const int* __restrict__ n_dev, i
     return m > n_cap ? 0 : m;
 }
 
+// Bitonic sort of 4096 (score, index) pairs by one workgroup, four consecutive positions per thread: the exchange partner of
+// position i in a pass of stride j is i ^ j -- inside the thread for j < 4, in another lane of the same wavefront for j < 256
+// (a cross-lane shuffle, no barrier), in another wave only for j >= 256 (through LDS: 10 of the 78 passes).
+__device__ __forceinline__ bool nms_before(float a, int ia, float b, int ib) {   // "a precedes b" in the final descending order
+    return (a > b) || (a == b && ia > ib) || (b != b && a == a);
+}
+
 __global__ __launch_bounds__(1024) void k_nms_sort(const float* __restrict__ scores, int n, int* __restrict__ order, const int* __restrict__ n_dev,
                                                    int n_cap) {
     __shared__ float key[NMS_MAX];
     __shared__ int idx[NMS_MAX];
     n = nms_count(n, n_dev, n_cap);
-    int m = 1;
-    while (m < n) m <<= 1;
-    for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        key[i] = i < n ? scores[i] : -__builtin_inff();
-        idx[i] = i < n ? i : -1;
+    const int t = threadIdx.x;
+    float kv[4];
+    int iv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * t + r;
+        kv[r] = i < n ? scores[i] : -__builtin_inff();   // padding (-inf, -1) sinks to the end
+        iv[r] = i < n ? i : -1;
     }
-    __syncthreads();
-    // descending by (score, index); padding (-inf, -1) sinks to the end
-    for (int k = 2; k <= m; k <<= 1) {
+    for (int k = 2; k <= NMS_MAX; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < m; i += blockDim.x) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const float a = key[i], b = key[p];
-                    const int ia = idx[i], ib = idx[p];
-                    // "a before b" in the final descending order?
-                    const bool a_first = (a > b) || (a == b && ia > ib) || (b != b && a == a);
-                    const bool desc = ((i & k) == 0);
-                    if (desc ? !a_first : a_first) {
-                        key[i] = b; key[p] = a;
-                        idx[i] = ib; idx[p] = ia;
+            if (j < 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = r ^ j;
+                    if (q > r) {
+                        const int i = 4 * t + r;
+                        const bool desc = (i & k) == 0;
+                        const bool a_first = nms_before(kv[r], iv[r], kv[q], iv[q]);
+                        if (desc ? !a_first : a_first) {
+                            const float tk = kv[r]; kv[r] = kv[q]; kv[q] = tk;
+                            const int ti = iv[r]; iv[r] = iv[q]; iv[q] = ti;
+                        }
                     }
                 }
+            } else if (j < 256) {
+                const int lj = j >> 2;   // lane distance
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ok = __shfl_xor(kv[r], lj);
+                    const int oi = __shfl_xor(iv[r], lj);
+                    const int i = 4 * t + r;
+                    const bool lower = (i & j) == 0;                 // this thread holds the lower position of the pair
+                    const bool desc = (i & k) == 0;
+                    const bool mine_first = nms_before(kv[r], iv[r], ok, oi);
+                    // the lower position keeps the element that precedes (descending block) / follows (ascending block)
+                    const bool keep_mine = (lower == desc) ? mine_first : !mine_first;
+                    if (!keep_mine) { kv[r] = ok; iv[r] = oi; }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { key[4 * t + r] = kv[r]; idx[4 * t + r] = iv[r]; }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 4 * t + r, p = i ^ j;
+                    const float ok = key[p];
+                    const int oi = idx[p];
+                    const bool lower = (i & j) == 0;
+                    const bool desc = (i & k) == 0;
+                    const bool mine_first = nms_before(kv[r], iv[r], ok, oi);
+                    const bool keep_mine = (lower == desc) ? mine_first : !mine_first;
+                    if (!keep_mine) { kv[r] = ok; iv[r] = oi; }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) order[i] = idx[i];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (4 * t + r < n) order[4 * t + r] = iv[r];
 }
 
 __device__ __forceinline__ float box_volume(const float* b) { return (b[3] - b[0]) * (b[4] - b[1]) * (b[5] - b[2]); }
