@@ -86,7 +86,9 @@ def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: 
         mt = (m + 127) // 128
         big = mt * ((cout + 127) // 128)
         wide = mt * ((cout + 255) // 256)                        # 128 x 256 tiles
-        if cout > 128 and wide * max(1, min(32, k_iters // 24)) >= 192:
+        if k_iters <= 4 and not transposed:                      # 64- / 128-channel 1x1 layers are HBM-bound: the small tile keeps the most loads in flight
+            tile = 64                                            # (same answer in the cfg1, cfg2 and cfg5 sweeps)
+        elif cout > 128 and wide * max(1, min(32, k_iters // 24)) >= 192:
             tile = 3256 if (halo_ok and mt >= 64) else 128256    # halo-stationary when the layer has taps to share
         elif big >= 120 and cout > 64:
             tile = 128

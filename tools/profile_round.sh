@@ -22,5 +22,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_tstats -o run -- 
 python3 $R/tools/summarise_profile.py stats /tmp/p_tstats $R/gpurun_out/prof_${TAG}_train_cfg3_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python3 tools/bench_train.py --steps 20 --warmup 3 (23 steps; MIOpen find-mode trial kernels of the warm-up excluded)" --exclude=naive_conv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_tfetch -o run -- python3 $R/tools/bench_train.py --steps 3 --warmup 3 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_twrite -o run -- python3 $R/tools/bench_train.py --steps 3 --warmup 3 > /dev/null 2>&1
-python3 $R/tools/summarise_profile.py pmc /tmp/p_tfetch /tmp/p_twrite $R/gpurun_out/prof_${TAG}_train_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/bench_train.py --steps 3 --warmup 3 (two separate passes)"
+python3 $R/tools/summarise_profile.py pmc /tmp/p_tfetch /tmp/p_twrite $R/gpurun_out/prof_${TAG}_train_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/bench_train.py --steps 3 --warmup 3 (two separate passes)" --workload=cfg3-train
 echo done

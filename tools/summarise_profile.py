@@ -132,8 +132,9 @@ if __name__ == "__main__":
     elif mode == "counters":
         counters(sys.argv[2], sys.argv[3], command=" ".join(sys.argv[4:]))
     elif mode == "pmc":
-        extra = sys.argv[5:]
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4], command=extra[0] if extra else "",
+        wl = [a.split("=", 1)[1] for a in sys.argv[5:] if a.startswith("--workload=")]
+        extra = [a for a in sys.argv[5:] if not a.startswith("--workload=")]
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], command=extra[0] if extra else "", workload=wl[0] if wl else "cfg2",
             algorithmic_bytes=int(extra[1]) if len(extra) > 1 else None)
     else:
         raise SystemExit(__doc__)

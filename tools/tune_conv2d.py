@@ -22,10 +22,24 @@ LAYERS = [  # name, cin, cout, (n,h,w), k, stride, residual
     ("fpn.out0 3x3 256->256", 256, 256, (50, 60, 80), 3, 1, False),
 ]
 
+def layers_for(n, h, w):
+    """ResNet bottleneck + FPN layer shapes for n views of h x w pixels (stage i runs at h/4/2^i x w/4/2^i)."""
+    out = []
+    for i, (cin, mid) in enumerate(((256, 64), (512, 128), (1024, 256), (2048, 512))):
+        hh, ww = -(-h // (4 << i)), -(-w // (4 << i))
+        out += [(f"l{i+1}.conv1 1x1 {cin}->{mid}", cin, mid, (n, hh, ww), 1, 1, False), (f"l{i+1}.conv2 3x3 {mid}->{mid}", mid, mid, (n, hh, ww), 3, 1, False),
+                (f"l{i+1}.conv3 1x1 {mid}->{cin} +res", mid, cin, (n, hh, ww), 1, 1, True)]
+    out += [("fpn.lat0 1x1 256->256", 256, 256, (n, h // 4, w // 4), 1, 1, False), ("fpn.out0 3x3 256->256", 256, 256, (n, h // 4, w // 4), 3, 1, False)]
+    return out
+
+
 def main():
     from nerfdet_amd import conv3d as C3
+    global LAYERS
     if len(sys.argv) > 1:
         C3.set_arithmetic(sys.argv[1])
+    if len(sys.argv) > 4:          # tune_conv2d.py <arithmetic> <n_views> <H> <W>
+        LAYERS = layers_for(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
     tiles = (64, 128, 12864, 128256, 3128, 3256, 3257) if C3.ARITHMETIC in ("bf16x3", "bf16") else (64, 128)
     print("arithmetic", C3.ARITHMETIC, flush=True)
     dev = torch.device("cuda")

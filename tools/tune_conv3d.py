@@ -22,10 +22,23 @@ LAYERS = [  # name, cin, cout, grid(in), k, stride, transposed
     ("head 128->25 @40x40x16", 128, 25, (40, 40, 16), 3, 1, False),
 ]
 
+def layers_for(gx, gy, gz):
+    """FastIndoorImVoxelNeck + head layer shapes on a gx x gy x gz voxel grid."""
+    g0, g1, g2 = (gx, gy, gz), (gx // 2, gy // 2, gz // 2), (gx // 4, gy // 4, gz // 4)
+    return [("down0.conv 256->256", 256, 256, g0, 3, 1, False), ("out0 256->128", 256, 128, g0, 3, 1, False), ("down1.conv1 256->512 s2", 256, 512, g0, 3, 2, False),
+            ("down1.conv2 512->512", 512, 512, g1, 3, 1, False), ("down1.ds 1x1 s2 256->512", 256, 512, g0, 1, 2, False), ("out1 512->128", 512, 128, g1, 3, 1, False),
+            ("down2.conv1 512->1024 s2", 512, 1024, g1, 3, 2, False), ("down2.conv2 1024->1024", 1024, 1024, g2, 3, 1, False), ("out2 1024->128", 1024, 128, g2, 3, 1, False),
+            ("up2.convT 1024->512", 1024, 512, g2, 2, 2, True), ("up1.convT 512->256", 512, 256, g1, 2, 2, True), ("head0 128->25", 128, 25, g0, 3, 1, False),
+            ("head1 128->25", 128, 25, g1, 3, 1, False), ("head2 128->25", 128, 25, g2, 3, 1, False)]
+
+
 def main():
     from nerfdet_amd import conv3d as C3
+    global LAYERS
     if len(sys.argv) > 1:
         C3.set_arithmetic(sys.argv[1])
+    if len(sys.argv) > 4:          # tune_conv3d.py <arithmetic> <X> <Y> <Z>
+        LAYERS = layers_for(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
     tiles = (64, 128, 12864, 128256, 3128, 3256, 3257) if C3.ARITHMETIC in ("bf16x3", "bf16") else (64, 128)
     print("arithmetic", C3.ARITHMETIC, flush=True)
     dev = torch.device("cuda")
