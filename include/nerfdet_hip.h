@@ -270,6 +270,20 @@ int ndet_conv_ndhwc_bf16(const float* in, const uint16_t* w_planes, float* out, 
                          const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
                          void* workspace, void* stream);
 
+/* Convolution + chained 1x1 convolution in one launch: out = act3(bn3(W3 . relu(bn1(conv(in)))) + residual), the intermediate (Cmid = 64 or
+ * 128 channels, ALL of them in one 128-row tile) never leaves the CU.  Replaces the conv2 -> bn2 -> relu -> conv3 -> bn3 -> (+identity) ->
+ * relu tail of the ResNet bottlenecks the detector runs as `self.backbone(img)` in mmdet3d/models/detectors/nerfdet.py:140 (mmdet's
+ * resnet.py Bottleneck.forward; third-party, restated): in stages 1 / 2 the intermediate is 61 / 31 MB per block at 50 views 240x320.
+ * in (D,H,W,Cin) fp32 channels-last (2D: D = batch, kernel[0] = 1); w_planes / w3_planes: bf16 planes of ndet_split_weights_bf16x3 for
+ * the (taps, Cmid, Cin) and (1, Cout, Cmid) packed weights; scale1/shift1, scale3/shift3: folded BatchNorm (null = identity); residual
+ * (M, Cout) or null; relu3: 0 none, 1 after the residual add, 2 before it; max_order 2: six products (fp32-class), 0: one (bf16).
+ * Cin % 32 == 0, Cout % 64 == 0.  Same arithmetic as the two ndet_conv_ndhwc_split launches it replaces except that the intermediate is
+ * not rounded through memory (it is the same fp32 value). */
+int ndet_conv_chain_split(const float* in, const uint16_t* w_planes, int D, int H, int W, int Cin, int Cmid, const int* kernel,
+                          const int* stride, const int* pad, const float* scale1, const float* shift1, const uint16_t* w3_planes,
+                          int Cout, const float* scale3, const float* shift3, const float* residual, int relu3, float* out,
+                          int max_order, void* stream);
+
 /* Experimental fp32-class arithmetic for the halo-stationary tiles (stride-1 same-padded multi-tap layers: the 3x3 / 3x3x3
  * convolutions of mmdet3d/models/necks/imvoxelnet.py:22-67,233-260 and of the FPN / ResNet): operands as fp16 PAIRS, three MFMA
  * products per multiply instead of six.  The caller pre-scales both tensors by powers of two towards 2^15 (weights: `scale` of

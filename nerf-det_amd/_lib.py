@@ -56,6 +56,7 @@ SIGNATURES = {
     "ndet_conv_ndhwc_f16x2": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P], c_int),
     "ndet_split_weights_bf16x3_torch": ([_P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_conv_ndhwc_split": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P], c_int),
+    "ndet_conv_chain_split": ([_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P], c_int),
     "ndet_conv_ndhwc_bf16": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_level_valid": ([_P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_select_candidates": ([c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P], c_int),

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .conv3d import bn_relu_maxpool_nhwc, conv2d_nhwc, packed
+from .conv3d import bn_relu_maxpool_nhwc, chain_ok, conv2d_chain_nhwc, conv2d_nhwc, packed
 from .conv_train import conv_forward
 from .registry import BACKBONES, NECKS
 
@@ -47,9 +47,12 @@ class Bottleneck(nn.Module):
         """Inference form on (N,H,W,C): every conv carries its frozen BatchNorm, ReLU and (last one) the residual
         add in the MFMA kernel's epilogue -- 4 kernels instead of 4 convs + 10 elementwise passes."""
         y = conv2d_nhwc(x, packed([self.conv1], self.bn1), relu=1)
-        y = conv2d_nhwc(y, packed([self.conv2], self.bn2), relu=1)
         idt = x if self.downsample is None else conv2d_nhwc(x, packed([self.downsample[0]], self.downsample[1]))
-        return conv2d_nhwc(y, packed([self.conv3], self.bn3), residual=idt, relu=1)
+        pk2, pk3 = packed([self.conv2], self.bn2), packed([self.conv3], self.bn3)
+        if chain_ok(pk2, pk3):          # stages 1 / 2: the 64- / 128-channel intermediate never leaves the CU
+            return conv2d_chain_nhwc(y, pk2, pk3, residual=idt, relu=1)
+        y = conv2d_nhwc(y, pk2, relu=1)
+        return conv2d_nhwc(y, pk3, residual=idt, relu=1)
 
 
 @BACKBONES.register_module()

@@ -301,6 +301,48 @@ def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = No
     return out
 
 
+CHAIN_BOTTLENECKS = True    # conv2 -> conv3 of the 64- / 128-channel bottlenecks in one launch (k_conv_split_chain)
+
+
+def chain_ok(pk: dict, pk3: dict) -> bool:
+    """The chained kernel holds ALL output channels of the first convolution in one 128 x 64 / 128 x 128 tile and multiplies them by a
+    1x1 layer: a 2D convolution to 64 / 128 channels followed by a stride-1 1x1 layer to a multiple of 64, in the bf16 family."""
+    return (CHAIN_BOTTLENECKS and ARITHMETIC in ("bf16x3", "bf16") and pk["ndim"] == 2 and pk3["ndim"] == 2 and pk["cout"] in (64, 128)
+            and not pk["transposed"] and tuple(pk3["kernel"]) == (1, 1) and tuple(pk3["strides"]) == (1, 1) and pk3["cin"] == pk["cout"]
+            and pk3["cout"] % 64 == 0 and pk["cin"] % 32 == 0 and pk["scale"] is not None and pk3["scale"] is not None)
+
+
+def conv2d_chain_nhwc(x: torch.Tensor, pk: dict, pk3: dict, residual: Optional[torch.Tensor] = None, relu: int = 1) -> torch.Tensor:
+    """relu_mode(bn3(conv1x1(relu(bn(conv(x))))) + residual) in ONE launch (csrc/conv_split_kernels.hip::k_conv_split_chain): conv2 -> conv3 of a
+    ResNet bottleneck without the intermediate's round trip through HBM.  x (N,H,W,Cin) contiguous fp32 -> (N,OH,OW,pk3 cout)."""
+    if not x.is_cuda:
+        raise RuntimeError("nerfdet_amd.conv3d: tensors must live on the GPU (no CPU fallback)")
+    assert chain_ok(pk, pk3) and x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+    n, h, w, cin = x.shape
+    assert cin == pk["cin"], (cin, pk["cin"])
+    (kh, kw), (sh, sw), (ph, pw), mid, cout = pk["kernel"], pk["strides"], pk["pads"], pk["cout"], pk3["cout"]
+    oh, ow = (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
+    out = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        assert tuple(residual.shape) == tuple(out.shape) and residual.is_contiguous(), (tuple(residual.shape), tuple(out.shape))
+    m = n * oh * ow
+    i3 = lambda a, b, c: (ctypes.c_int * 3)(a, b, c)
+    st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    lib = _lib.load()
+    p1, p3 = split_planes(pk), split_planes(pk3)
+    flops = 2 * m * mid * (cin * kh * kw + cout)
+    nbytes = 4 * (x.numel() + pk["w"].numel() + pk3["w"].numel() + out.numel() + (0 if residual is None else residual.numel()))
+    name = f"k_conv_split_chain<{mid}>"
+    thunk = lambda: check(lib.ndet_conv_chain_split(_ptr(x), _ptr(p1), n, h, w, cin, mid, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw), _ptr(pk["scale"]),
+                                                    _ptr(pk["shift"]), _ptr(p3), cout, _ptr(pk3["scale"]), _ptr(pk3["shift"]), _ptr(residual), relu,
+                                                    _ptr(out), 0 if ARITHMETIC == "bf16" else 2, st), "conv_chain_split")
+    if launch_hook is not None:
+        launch_hook(flops, thunk, name)
+    else:
+        trace.span(name, thunk, flops=flops, bytes=nbytes, kind="conv")
+    return out
+
+
 def bn_relu_maxpool_nhwc(x: torch.Tensor, bn: nn.BatchNorm2d) -> torch.Tensor:
     """x (N,H,W,C) contiguous -> MaxPool2d(3,2,1)(relu(bn_eval(x))) in one pass (ResNet stem tail)."""
     assert x.is_cuda and x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32

@@ -82,8 +82,11 @@ __device__ __forceinline__ void spl_split4_f16(const float4 v, float scale, uint
 }
 
 // ONE: the leading bf16 plane only, one product per multiply (bf16 autocast arithmetic).
-template <int BM, int BN, int WGM, int WGN, bool ONE = false>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dParams p, const uint16_t* __restrict__ wsplit) {
+// K walk of the unified tiles: fills acc (per-wave 32x32 MFMA tiles) for GEMM rows m0.. and channels n0..; returns the transposed-conv tap
+// (blockIdx.z) in ztap.  Ends behind a barrier: the LDS operand planes are free for the epilogue.
+template <int BM, int BN, int WGM, int WGN, bool ONE>
+__device__ __forceinline__ void conv_split_mainloop(const Conv3dParams& p, const uint16_t* __restrict__ wsplit, uint16_t* lds16,
+                                                    f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int& ztap) {
     constexpr int NTHR = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN;   // per-wave tile
     constexpr int MT = WM / 32, NT = WN / 32;     // 32x32 MFMA tiles per wave
@@ -92,7 +95,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
     constexpr int AR = BM / RPA, BR = BN / RPB;
     static_assert(AR >= 1 && BR >= 1 && MT >= 1 && NT >= 1, "tile too small for the thread count");
     constexpr int APL = BM * SPL_RS, BPL = BN * SPL_RS;  // one plane, in bf16 elements
-    extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
     constexpr int NPL = ONE ? 1 : 3;
     uint16_t* As = lds16;               // [NPL][BM][SPL_RS]
     uint16_t* Bs = lds16 + NPL * APL;   // [NPL][BN][SPL_RS]
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
     const int taps = p.transposed ? 1 : p.kd * p.kh * p.kw;
     const int n_iters_all = taps * cin_steps;
     int it_begin = 0, it_end = n_iters_all;
-    int ztap = 0;
+    ztap = 0;
     if (p.transposed) {
         ztap = blockIdx.z;
     } else if (p.splits > 1) {
@@ -130,7 +132,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
         vd[i] = mm / (ow_ * oh_);
     }
 
-    f32x16 acc[MT][NT];
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -252,6 +253,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
         if (more) store_tile();
         __syncthreads();
     }
+}
+
+template <int BM, int BN, int WGM, int WGN, bool ONE = false>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dParams p, const uint16_t* __restrict__ wsplit) {
+    constexpr int NTHR = 64 * WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    f32x16 acc[MT][NT];
+    int ztap;
+    conv_split_mainloop<BM, BN, WGM, WGN, ONE>(p, wsplit, lds16, acc, ztap);
 
     // ---- epilogue: accumulators -> LDS (one wave-row of the tile at a time) -> fused row-wise stores ----
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -270,6 +285,177 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
         __syncthreads();
         conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, ztap, blockIdx.z);
         __syncthreads();
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Convolution + chained 1x1 convolution in one launch: out = act3(bn3(W3 . relu(bn1(conv(x)))) + residual) -- conv2 -> conv3 of a
+// ResNet bottleneck (mmdet's Bottleneck.forward behind nerfdet.py:140; the 64- / 128-channel intermediate of stages 1 / 2 is 61 MB at
+// cfg2 and would be written and read back once per block).  The first convolution runs as above on a 128 x MID tile holding ALL
+// of its output channels; its accumulators go through BN + ReLU and the bf16 split straight into LDS in the A-operand layout
+// (three planes, 128 rows x MID), and the same four waves multiply that image by W3: every wave owns 32 CTW-column slices of the
+// output, keeps the slice's W3 fragments in registers (read from L2 once per workgroup, never staged) and walks the four 32-row
+// tiles.  The epilogue works in the MFMA's own C layout: a register of the 32 x 32 tile is 32 consecutive channels of one row = one
+// whole 128-byte line for the residual read and the store.
+// ------------------------------------------------------------------------------------------------
+struct ConvChain {
+    const uint16_t* w3;    // (1, MID/32, 3, Cout3, 32) bf16 planes
+    const float* scale3;   // (Cout3) or null
+    const float* shift3;
+    const float* res;      // (M, Cout3) or null
+    float* out;            // (M, Cout3)
+    int Cout3;
+    int relu3;             // 0 none, 1 ReLU last, 2 ReLU before the residual add
+};
+
+template <int MID, bool ONE>
+__global__ __launch_bounds__(256, MID == 64 ? 3 : 2) void k_conv_split_chain(const Conv3dParams p, const uint16_t* __restrict__ wsplit, const ConvChain c) {
+    constexpr int BM = 128, BN = MID, WGM = 2, WGN = 2;
+    constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
+    constexpr int NPL = ONE ? 1 : 3;
+    constexpr int YRS = MID;              // LDS rows of the intermediate are unpadded; the 16-byte chunk index is XORed with row & 7 (fragment reads
+    constexpr int HALVES = MID == 128 ? 2 : 1;   // 128 channels: the intermediate is chained 64 rows at a time (48 KB of LDS either way)
+    constexpr int RH = BM / HALVES;
+    constexpr int YPL = RH * YRS;         // of 32 consecutive rows at one chunk then cover all banks)
+    constexpr int NRT = RH / 32;
+    constexpr int KS = MID / 16;          // 16-wide K slices of the chained GEMM
+    constexpr int KG = 4, NKG = KS / KG;  // K slices whose W3 fragments are register-resident at a time (KG x NPL x 4 VGPRs)
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM;
+    f32x16 acc[MT][NT];
+    int ztap;
+    conv_split_mainloop<BM, BN, WGM, WGN, ONE>(p, wsplit, lds16, acc, ztap);
+
+    // ---- intermediate: BN + ReLU, bf16 split, into LDS as the A operand of the chained GEMM ----
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    uint16_t* Y = lds16;
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    const int64_t w3pl = (int64_t)c.Cout3 * CBK;   // one plane of one 32-channel chunk, elements
+    const unsigned obytes = (unsigned)((int64_t)p.M * c.Cout3 * 4);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(c.res ? c.res : c.out), 0, obytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)c.out, 0, obytes, 0x00020000);
+    for (int h = 0; h < HALVES; ++h) {
+        if (HALVES == 1 || wm == h) {
+#pragma unroll
+            for (int ta = 0; ta < MT; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < NT; ++tb) {
+                    const int col = wn * WN + tb * 32 + (lane & 31);
+                    const float sc = p.scale ? p.scale[col] : 1.0f, sh = p.scale ? p.shift[col] : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        float a = acc[ta][tb][r] * sc + sh, b = acc[ta][tb][r + 1] * sc + sh;   // rows r and r + 1 of this lane's column
+                        if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+                        const int row = (HALVES == 1 ? wm * WM : 0) + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        uint16_t* da = Y + row * YRS + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7));
+                        uint16_t* db = Y + (row + 1) * YRS + ((((col >> 3) ^ ((row + 1) & 7)) << 3) | (col & 7));
+                        const uint32_t o0 = spl_pack(a, b);
+                        da[0] = (uint16_t)o0; db[0] = (uint16_t)(o0 >> 16);
+                        if (!ONE) {
+                            const float ra = a - spl_lo(o0), rb = b - spl_hi(o0);
+                            const uint32_t o1 = spl_pack(ra, rb);
+                            da[YPL] = (uint16_t)o1; db[YPL] = (uint16_t)(o1 >> 16);
+                            const uint32_t o2 = spl_pack(ra - spl_lo(o1), rb - spl_hi(o1));
+                            da[2 * YPL] = (uint16_t)o2; db[2 * YPL] = (uint16_t)(o2 >> 16);
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+
+        // ---- chained GEMM: (RH x MID) . W3 (MID x Cout3), one 32-column tile per wave and pass; the W3 fragments of KG K-slices are
+        // register-resident (all of them at MID = 64; at MID = 128 in two groups, with the pass's NRT accumulator tiles kept) ----
+        for (int cb = wave * 32; cb < c.Cout3; cb += 4 * 32) {
+            const int co = cb + frow;
+            const float sc3 = c.scale3 ? c.scale3[co] : 1.0f, sh3 = c.scale3 ? c.shift3[co] : 0.0f;
+            constexpr int NC2 = NKG == 1 ? 1 : NRT;
+            f32x16 c2[NC2];
+#pragma unroll
+            for (int rt = 0; rt < NC2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c2[rt][r] = 0.f;
+            auto load_b = [&](bf16x8 (&fb)[NPL][KG], int kg) {
+#pragma unroll
+                for (int k4 = 0; k4 < KG; ++k4)
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) {
+                        const int ks = kg * KG + k4;
+                        fb[pl][k4] = *reinterpret_cast<const bf16x8*>(c.w3 + ((int64_t)(ks >> 1) * 3 + pl) * w3pl + (int64_t)co * CBK + (ks & 1) * 16 + fk);
+                    }
+            };
+            auto mul = [&](f32x16& cc, const bf16x8 (&fb)[NPL][KG], int rt, int kg) {
+                const uint16_t* ya = Y + (rt * 32 + frow) * YRS;
+#pragma unroll
+                for (int k4 = 0; k4 < KG; ++k4) {
+                    bf16x8 fa[NPL];
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl)
+                        fa[pl] = *reinterpret_cast<const bf16x8*>(ya + pl * YPL + (((2 * (kg * KG + k4) + (lane >> 5)) ^ (frow & 7)) << 3));
+#pragma unroll
+                    for (int order = NPL - 1; order >= 0; --order)
+                        if (order <= p.max_order)
+#pragma unroll
+                            for (int pa = 0; pa <= order; ++pa) cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa], fb[order - pa][k4], cc, 0, 0, 0);
+                }
+            };
+            // residual reads and stores as buffer operations: the lane's part of the address is one VGPR for the whole pass, the row of
+            // register r rides in the scalar offset, rows past M fall outside the descriptor (reads return 0, stores are dropped)
+            const unsigned vo = (unsigned)(((int64_t)(m0 + h * RH + 4 * (lane >> 5)) * c.Cout3 + co) * 4);
+            auto load_res = [&](float (&rr)[16], int rt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((rt * 32 + (r & 3) + 8 * (r >> 2)) * c.Cout3 * 4));
+                    rr[r] = c.res ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rres, vo, so, 0)) : 0.0f;
+                }
+            };
+            auto finish = [&](const f32x16& cc, const float (&rr)[16], int rt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((rt * 32 + (r & 3) + 8 * (r >> 2)) * c.Cout3 * 4));
+                    float v = cc[r] * sc3 + sh3;
+                    if (c.relu3 == 2) v = fmaxf(v, 0.f);
+                    v += rr[r];
+                    if (c.relu3 == 1) v = fmaxf(v, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, vo, so, 0);
+                }
+            };
+            if constexpr (NKG == 1) {
+                bf16x8 fb[NPL][KG];
+                load_b(fb, 0);
+                float rn[16];                         // the residual of the NEXT row tile travels while this one is multiplied and stored
+                load_res(rn, 0);
+#pragma nounroll
+                for (int rt = 0; rt < NRT; ++rt) {
+                    mul(c2[0], fb, rt, 0);
+                    float rr[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rr[r] = rn[r];
+                    if (rt + 1 < NRT) load_res(rn, rt + 1);
+                    finish(c2[0], rr, rt);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c2[0][r] = 0.f;
+                }
+            } else {
+#pragma nounroll
+                for (int kg = 0; kg < NKG; ++kg) {
+                    bf16x8 fb[NPL][KG];
+                    load_b(fb, kg);
+#pragma unroll
+                    for (int rt = 0; rt < NRT; ++rt) mul(c2[rt], fb, rt, kg);
+                }
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) {
+                    float rr[16];
+                    load_res(rr, rt);
+                    finish(c2[rt], rr, rt);
+                }
+            }
+        }
+        if (h + 1 < HALVES) __syncthreads();
     }
 }
 
@@ -1104,3 +1290,63 @@ static int conv_split_entry(const char* fn, int max_order, float xscale, const f
     NDET_REQUIRE(p.splits == 1 || workspace != nullptr, NDET_E_INVALID, "%s: split-K needs a workspace", fn);
     return conv_split_launch(p, tile, (hipStream_t)stream, fn);
 }
+
+template <int MID, bool ONE>
+static int chain_launch(const Conv3dParams& p, const ConvChain& c, hipStream_t st, const char* fn) {
+    constexpr int NPL = ONE ? 1 : 3;
+    size_t lds = (size_t)NPL * (128 + MID) * SPL_RS * sizeof(uint16_t);
+    const size_t y = (size_t)NPL * (MID == 128 ? 64 : 128) * MID * sizeof(uint16_t);
+    if (y > lds) lds = y;
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_conv_split_chain<MID, ONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL((k_conv_split_chain<MID, ONE>), dim3((p.M + 127) / 128), dim3(256), lds, st, p, (const uint16_t*)p.w, c);
+    return NDET_OK;
+}
+
+extern "C" int ndet_conv_chain_split(const float* in, const uint16_t* w_planes, int D, int H, int W, int Cin, int Cmid, const int* kernel,
+                                     const int* stride, const int* pad, const float* scale1, const float* shift1, const uint16_t* w3_planes,
+                                     int Cout, const float* scale3, const float* shift3, const float* residual, int relu3, float* out,
+                                     int max_order, void* stream) {
+    const char* fn = "ndet_conv_chain_split";
+    NDET_REQUIRE(in && w_planes && w3_planes && out && kernel && stride && pad, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
+    NDET_REQUIRE((scale1 == nullptr) == (shift1 == nullptr) && (scale3 == nullptr) == (shift3 == nullptr), NDET_E_INVALID, "%s: scale and shift go together", fn);
+    NDET_REQUIRE(Cmid == 64 || Cmid == 128, NDET_E_UNSUPPORTED, "%s: the intermediate must have 64 or 128 channels (got %d)", fn, Cmid);
+    NDET_REQUIRE(Cin % CBK == 0 && Cout % 64 == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d, Cout=%d of 64", fn, Cin, CBK, Cout);
+    NDET_REQUIRE(relu3 >= 0 && relu3 <= 2 && (max_order == 0 || max_order == 2), NDET_E_INVALID, "%s: bad relu mode / arithmetic", fn);
+    NDET_REQUIRE((((uintptr_t)in | (uintptr_t)w_planes | (uintptr_t)w3_planes) & 15) == 0, NDET_E_UNSUPPORTED, "%s: in / weights must be 16-byte aligned", fn);
+    Conv3dParams p;
+    p.in = in; p.w = reinterpret_cast<const float*>(w_planes); p.out = nullptr; p.scale = scale1; p.shift = shift1; p.res = nullptr; p.partial = nullptr;
+    p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cmid; p.relu = 1; p.max_order = max_order; p.xscale = 1.0f;
+    for (int a = 0; a < 3; ++a)
+        NDET_REQUIRE(kernel[a] >= 1 && kernel[a] <= 7 && stride[a] >= 1 && stride[a] <= 4 && pad[a] >= 0 && pad[a] < kernel[a], NDET_E_UNSUPPORTED,
+                     "%s: kernel/stride/pad out of range on axis %d", fn, a);
+    p.transposed = 0;
+    p.kd = kernel[0]; p.kh = kernel[1]; p.kw = kernel[2];
+    p.sd = stride[0]; p.sh = stride[1]; p.sw = stride[2];
+    p.pd = pad[0]; p.ph = pad[1]; p.pw = pad[2];
+    p.OD = (D + 2 * p.pd - p.kd) / p.sd + 1;
+    p.OH = (H + 2 * p.ph - p.kh) / p.sh + 1;
+    p.OW = (W + 2 * p.pw - p.kw) / p.sw + 1;
+    NDET_REQUIRE(p.OD > 0 && p.OH > 0 && p.OW > 0, NDET_E_INVALID, "%s: empty output", fn);
+    NDET_REQUIRE((int64_t)p.OD * p.OH * p.OW < ((int64_t)1 << 31) && (int64_t)D * H * W * Cin < ((int64_t)1 << 40), NDET_E_UNSUPPORTED, "%s: tensor too large", fn);
+    p.M = p.OD * p.OH * p.OW;
+    NDET_REQUIRE(((int64_t)p.M + 128) * Cout * 4 < ((int64_t)1 << 32), NDET_E_UNSUPPORTED, "%s: the output is addressed with 32-bit byte offsets (< 4 GB)", fn);
+    p.splits = 1; p.res_up2 = 0; p.RH = p.RW = 0;
+    ConvChain c;
+    c.w3 = w3_planes; c.scale3 = scale3; c.shift3 = shift3; c.res = residual; c.out = out; c.Cout3 = Cout; c.relu3 = relu3;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (Cmid == 64) rc = max_order == 0 ? chain_launch<64, true>(p, c, st, fn) : chain_launch<64, false>(p, c, st, fn);
+    else rc = max_order == 0 ? chain_launch<128, true>(p, c, st, fn) : chain_launch<128, false>(p, c, st, fn);
+    if (rc != NDET_OK) return rc;
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
+

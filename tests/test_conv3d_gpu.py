@@ -342,3 +342,53 @@ def test_bf16_arithmetic_is_a_bf16_rounded_convolution(device, cin, cout, grid, 
     scale = float(ref.abs().max())
     assert float((got - ref).abs().max()) <= 2e-5 * scale
     assert float((got - full).abs().max()) >= 1e-4 * scale
+
+
+@pytest.mark.parametrize("cin,mid,cout,nhw,k,stride,use_res,relu3", [
+    (64, 64, 256, (3, 13, 17), 3, 1, True, 1),      # stage-1 bottleneck tail, ragged last tile
+    (64, 64, 256, (2, 12, 16), 3, 1, False, 0),     # no residual, no final ReLU
+    (128, 128, 512, (2, 13, 18), 3, 2, True, 1),    # stage-2 first block: stride-2 3x3, 128-channel intermediate
+    (128, 128, 512, (2, 10, 12), 3, 1, True, 2),    # ReLU before the residual add
+    (256, 64, 128, (2, 9, 11), 1, 1, True, 1),      # 1x1 -> 1x1
+])
+def test_conv_chain_matches_torch_fp32_and_the_two_launches(device, cin, mid, cout, nhw, k, stride, use_res, relu3):
+    """k_conv_split_chain (conv -> BN -> ReLU -> 1x1 conv -> BN -> (+residual) -> ReLU in one launch) against PyTorch-CPU fp32 and against the
+    two separate launches it replaces: same arithmetic, the intermediate is the same fp32 value -> equal to rounding of the fp32 sums."""
+    from nerfdet_amd import conv3d
+    from nerfdet_amd.conv3d import conv2d_chain_nhwc, conv2d_nhwc, packed, chain_ok
+    torch.manual_seed(cin + mid + cout + k)
+    c2, c3 = nn.Conv2d(cin, mid, k, stride, k // 2, bias=False), nn.Conv2d(mid, cout, 1, bias=False)
+    b2, b3 = nn.BatchNorm2d(mid).eval(), nn.BatchNorm2d(cout).eval()
+    with torch.no_grad():
+        for bn in (b2, b3):
+            bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+    x = torch.randn(*nhw, cin)
+    with torch.no_grad():
+        y = b3(c3(F.relu(b2(c2(x.permute(0, 3, 1, 2))))))
+        res = torch.randn_like(y) if use_res else None
+        if relu3 == 2:
+            y = F.relu(y)
+        if res is not None:
+            y = y + res
+        if relu3 == 1:
+            y = F.relu(y)
+        ref = y.permute(0, 2, 3, 1).contiguous()
+        for m in (c2, c3, b2, b3):
+            m.to(device)
+        pk2, pk3 = packed([c2], b2), packed([c3], b3)
+        assert chain_ok(pk2, pk3)
+        rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(device)
+        got = conv2d_chain_nhwc(x.to(device), pk2, pk3, residual=rd, relu=relu3)
+        two = conv2d_nhwc(conv2d_nhwc(x.to(device), pk2, relu=1), pk3, residual=rd, relu=relu3)
+        prev = conv3d.set_arithmetic("bf16")
+        try:
+            got16 = conv2d_chain_nhwc(x.to(device), pk2, pk3, residual=rd, relu=relu3)
+            two16 = conv2d_nhwc(conv2d_nhwc(x.to(device), pk2, relu=1), pk3, residual=rd, relu=relu3)
+        finally:
+            conv3d.set_arithmetic(prev)
+    scale = max(1.0, float(ref.abs().max()))
+    assert got.shape == ref.shape
+    assert float((got.cpu() - ref).abs().max()) <= 2e-5 * scale
+    assert float((got - two).abs().max()) <= 4e-6 * scale
+    assert float((got16 - two16).abs().max()) <= 4e-6 * scale          # one-product arithmetic: same bf16-rounded operands either way
+    assert float((got16.cpu() - ref).abs().max()) > 1e-4 * scale          # ... and really one product

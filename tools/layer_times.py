@@ -6,6 +6,9 @@ import bench
 from nerfdet_amd import trace
 
 w = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
+if len(sys.argv) > 2 and sys.argv[2] == "nochain":     # layer_times.py cfg2 nochain: conv2 / conv3 of the bottlenecks as two launches
+    from nerfdet_amd import conv3d
+    conv3d.CHAIN_BOTTLENECKS = False
 dev = torch.device("cuda")
 det = bench.build_model(w).to(dev)
 batch = bench.to_device(bench.synth_batch(w, 0), dev)
