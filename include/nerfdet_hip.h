@@ -321,11 +321,12 @@ int ndet_target_rays(const uint8_t* frames_bgr, const int* target_ids, int n_tar
 
 /* Weight-gradient staging for the training-time convolutions (autograd of nn.Conv3d / nn.Conv2d in
  * mmdet3d/models/necks/imvoxelnet.py:22-67,233-260 and of the third-party ResNet/FPN layers): channels-last x (D,H,W,C) -> rows
- * out[t - t0][c][j] = xpad[c][j + off(t) - margin] over the zero-padded flattened grid (pads pd,ph,pw), taps t0 .. t0+n_taps-1 of a
- * (kd,kh,kw) stride-1 kernel; every element of out (n_taps, C, lrow) is written (zeros in halo and margins).  With these rows the
- * weight gradient is one GEMM over j on ndet_conv_ndhwc_split (nerfdet_amd/conv_train.py). */
-int ndet_wgrad_rows(const float* x_ndhwc, int D, int H, int W, int C, int kd, int kh, int kw, int pd, int ph, int pw, int t0,
-                    int n_taps, int margin, int lrow, float* out, void* stream);
+ * out[t - t0][c][j] = x[stride * o(j) + tap(t) - pad][c] over the flattened OUTPUT grid of the (kernel, stride, pad) convolution, taps
+ * t0 .. t0+n_taps-1; every element of out (n_taps, C, lrow) is written (zeros where the tap reads padding and for j past the grid;
+ * lrow >= OD*OH*OW).  With these rows (and dY staged by the same call with a 1x1x1 kernel) the weight gradient is one GEMM over j on
+ * ndet_conv_ndhwc_split, for any stride (nerfdet_amd/conv_train.py). */
+int ndet_wgrad_rows(const float* x_ndhwc, int D, int H, int W, int C, const int* kernel, const int* stride, const int* pad, int t0,
+                    int n_taps, int lrow, float* out, void* stream);
 
 /* ---- backward passes (training).  The reference obtains these from autograd over its materialised tensors; each
  * entry point names the forward statement it differentiates.  Scatter targets must be zero-initialised by the caller;

@@ -94,7 +94,7 @@ class RayViewStats(torch.autograd.Function):
         glob, pm, vc = rays.ray_view_stats(xyz, train_imgs, train_cameras, f)
         cams = train_cameras.squeeze(0) if train_cameras.dim() == 3 else train_cameras
         ke, h, w = rays._camera_matrices(cams)
-        ctx.save_for_backward(f, xyz.detach().float().reshape(-1, 3).contiguous(), ke.to(xyz.device))
+        ctx.save_for_backward(f, xyz.detach().float().reshape(-1, 3).contiguous(), rays._to_device(ke, xyz.device))
         ctx.hw = (h, w)
         ctx.mark_non_differentiable(pm, vc)
         return glob, pm, vc

@@ -37,7 +37,7 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         # training on the GPU: the stride-1 convolutions run on the MFMA kernels, forward and backward (nerfdet_amd/conv_train.py)
-        idt = x if self.downsample is None else self.downsample(x)
+        idt = x if self.downsample is None else self.downsample[1](conv_forward(self.downsample[0], x))
         out = F.relu(self.bn1(conv_forward(self.conv1, x)), inplace=True)
         out = F.relu(self.bn2(conv_forward(self.conv2, out)), inplace=True)
         out = self.bn3(conv_forward(self.conv3, out))

@@ -242,7 +242,8 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
     if tr:
         od, oh, ow = 2 * d, 2 * h, 2 * w
     else:
-        pad = k // 2
+        pad = int(pk["pads"][0]) if "pads" in pk else k // 2
+        assert pad == k // 2 or ARITHMETIC in ("bf16x3", "bf16"), "the fp32-MFMA family pads by k // 2"
         od, oh, ow = ((v + 2 * pad - k) // s + 1 for v in (d, h, w))
     out = torch.empty((od, oh, ow, cout), dtype=torch.float32, device=x.device)
     if residual is not None:
@@ -251,7 +252,7 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
     m = d * h * w if tr else od * oh * ow
     flops = 2 * m * cout * cin * (1 if tr else k ** 3) * (8 if tr else 1)
     if ARITHMETIC in ("bf16x3", "bf16"):
-        kk, ss, pp = ((2, 2, 2), (2, 2, 2), (0, 0, 0)) if tr else ((k,) * 3, (s,) * 3, (k // 2,) * 3)
+        kk, ss, pp = ((2, 2, 2), (2, 2, 2), (0, 0, 0)) if tr else ((k,) * 3, (s,) * 3, (pad,) * 3)
         return _conv_split(x, pk, out, (d, h, w), kk, ss, pp, tr, residual, False, relu, splits, tile, m,
                            (cin // 32) * (1 if tr else k ** 3), flops)
     if tr:

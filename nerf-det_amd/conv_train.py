@@ -1,19 +1,19 @@
 """Training-time convolutions on the hand-written MFMA kernels (SURVEY.md 8a rows A13/A14 in ``forward_train``).
 
-Forward, data gradient and weight gradient of the stride-1 same-padded convolutions -- nine of the thirteen convolutions of
-``FastIndoorImVoxelNeck`` (mmdet3d/models/necks/imvoxelnet.py:22-67,233-260; 446 of its 490 GFLOP) and the stride-1 layers of
-the trainable ResNet stages / FPN -- all run on ``ndet_conv_ndhwc_split`` (csrc/conv_split_kernels.hip), no new device code:
+Forward, data gradient and weight gradient of the same-padded convolutions -- the convolutions of ``FastIndoorImVoxelNeck``
+(mmdet3d/models/necks/imvoxelnet.py:22-67,233-260) and of the trainable ResNet stages / FPN -- run on ``ndet_conv_ndhwc_split``
+(csrc/conv_split_kernels.hip):
 
-  forward   y = conv(x, W)                                         the inference kernel, no epilogue
-  dgrad     dx = conv(dy, W'),  W'[ci, co, t] = W[co, ci, flip(t)]  the same kernel on the transposed, tap-flipped weight
-  wgrad     dW[t][co][ci] = sum_v dy[v][co] x[v + off(t)][ci]       ONE launch of the same kernel as a plain GEMM:
-            both tensors are laid out channel-major over the zero-padded, flattened voxel grid -- then a tap is a constant
-            shift of the contraction index -- the 27 (9, 1) shifted copies of x are stacked as GEMM rows (T*Cin, L), dy (Cout, L)
-            plays the "weight" operand (split into its bf16 planes once), and the contraction runs over the L padded voxels.
-            Rows read past their end only where dy is zero (halo and margins), so the wrap-around is harmless.
+  forward   y = conv(x, W)                                         the inference kernel, no epilogue (any stride)
+  dgrad     dx = conv(dy, W'),  W'[ci, co, t] = W[co, ci, flip(t)]  stride 1: the same kernel on the transposed, tap-flipped weight
+                                                                   (stride 2: the vendor library's data gradient)
+  wgrad     dW[t][co][ci] = sum_o dy[o][co] x[s o + t - p][ci]      ONE launch of the same kernel as a plain GEMM: both tensors are
+            staged channel-major over the flattened OUTPUT grid (csrc/pipeline_kernels.hip::k_wgrad_rows): the T copies of x, each
+            sampled at its tap's positions, are stacked as GEMM rows (T*Cin, L), dy (Cout, L) plays the "weight" operand (split into
+            its bf16 planes once), and the contraction runs over the L output voxels -- for any stride.
 
-Strided convolutions, transposed convolutions and the tiny head convolutions stay on the vendor library.  BatchNorm in training
-mode (batch statistics, BasicBlock3dV2) is left to ATen on the same channels-last memory; nothing is copied between layouts."""
+Transposed convolutions stay on the vendor library.  BatchNorm in training mode (batch statistics, BasicBlock3dV2) is left to ATen on
+the same channels-last memory; nothing is copied between layouts."""
 from __future__ import annotations
 
 from typing import Sequence, Tuple
@@ -26,15 +26,16 @@ from . import conv3d as C
 Tensor = torch.Tensor
 
 
-def _raw_pack(w_taps_co_ci: Tensor, kernel: Sequence[int]) -> dict:
-    """Pack dict of nerfdet_amd.conv3d for a bare weight already in (taps, Cout, Cin) order: no BatchNorm, no bias, stride 1."""
+def _raw_pack(w_taps_co_ci: Tensor, kernel: Sequence[int], stride: int = 1, pads=None) -> dict:
+    """Pack dict of nerfdet_amd.conv3d for a bare weight already in (taps, Cout, Cin) order: no BatchNorm, no bias."""
     k = tuple(int(v) for v in kernel)
     ndim = len(k)
     return dict(w=w_taps_co_ci.contiguous().float(), scale=None, shift=None, cout=int(w_taps_co_ci.shape[1]), cin=int(w_taps_co_ci.shape[2]),
-                ksize=k[0], stride=1, transposed=False, kernel=k, strides=(1,) * ndim, pads=tuple(v // 2 for v in k), ndim=ndim)
+                ksize=k[0], stride=stride, transposed=False, kernel=k, strides=(stride,) * ndim,
+                pads=tuple(v // 2 for v in k) if pads is None else tuple(pads), ndim=ndim)
 
 
-def _train_pack(w: Tensor, kernel, adjoint: bool) -> dict:
+def _train_pack(w: Tensor, kernel, adjoint: bool, stride: int = 1, pads=None) -> dict:
     """Pack dict for the layer (or, ``adjoint``, for its data gradient) straight from the torch-layout weight: with the bf16x3
     kernels one launch writes the three bf16 planes (ndet_split_weights_bf16x3_torch); the fp32-MFMA family goes through the
     generic packer."""
@@ -44,7 +45,7 @@ def _train_pack(w: Tensor, kernel, adjoint: bool) -> dict:
         taps *= int(v)
     if C.ARITHMETIC not in ("bf16x3", "bf16"):
         if not adjoint:
-            return _raw_pack(C.pack_weight(w), kernel)
+            return _raw_pack(C.pack_weight(w), kernel, stride, pads)
         flip = w.flip(tuple(range(2, w.dim()))).transpose(0, 1)
         if cout % 32:
             flip = torch.nn.functional.pad(flip, (0, 0) * (w.dim() - 2) + (0, 32 - cout % 32))
@@ -57,8 +58,8 @@ def _train_pack(w: Tensor, kernel, adjoint: bool) -> dict:
     _lib.check(_lib.load().ndet_split_weights_bf16x3_torch(c_void_p(wc.data_ptr()), taps, cout, cin, int(adjoint), c_void_p(planes.data_ptr()),
                                                            c_void_p(torch.cuda.current_stream(w.device).cuda_stream)), "split_weights_torch")
     k = tuple(int(v) for v in kernel)
-    return dict(w=wc, w_split=planes, scale=None, shift=None, cout=no, cin=ki, ksize=k[0], stride=1, transposed=False, kernel=k,
-                strides=(1,) * len(k), pads=tuple(v // 2 for v in k), ndim=len(k))
+    return dict(w=wc, w_split=planes, scale=None, shift=None, cout=no, cin=ki, ksize=k[0], stride=stride, transposed=False, kernel=k,
+                strides=(stride,) * len(k), pads=tuple(v // 2 for v in k) if pads is None else tuple(pads), ndim=len(k))
 
 
 def _conv(x: Tensor, pk: dict) -> Tensor:
@@ -66,64 +67,80 @@ def _conv(x: Tensor, pk: dict) -> Tensor:
 
 
 def eligible(conv: nn.Module, x: Tensor) -> bool:
-    """Stride-1, odd, same-padded, un-dilated, un-grouped convolution whose input channel count the MFMA kernel steps through (a
-    multiple of 32), on a float32 GPU tensor."""
+    """Odd, same-padded (pad = k // 2), un-dilated, un-grouped convolution of uniform stride 1 or 2 whose input channel count the MFMA
+    kernel steps through (a multiple of 32), on a float32 GPU tensor."""
     if not isinstance(conv, (nn.Conv3d, nn.Conv2d)) or not x.is_cuda or x.dtype != torch.float32:
         return False
     k = conv.kernel_size
     if isinstance(conv, nn.Conv3d) and len(set(k)) != 1:
         return False
-    return (all(s == 1 for s in conv.stride) and all(d == 1 for d in conv.dilation) and conv.groups == 1
+    return (len(set(conv.stride)) == 1 and conv.stride[0] in (1, 2) and all(d == 1 for d in conv.dilation) and conv.groups == 1
             and all(v % 2 == 1 and p == v // 2 for v, p in zip(k, conv.padding)) and conv.padding_mode == "zeros"
             and conv.in_channels % 32 == 0)
 
 
-def _rows(x: Tensor, k3, pads, t0: int, n_taps: int, margin: int, lrow: int) -> Tensor:
-    """csrc/pipeline_kernels.hip::k_wgrad_rows: (D,H,W,C) -> (n_taps, C, lrow) shifted channel-major rows over the padded grid."""
+def _rows(x: Tensor, k3, stride3, pads, t0: int, n_taps: int, lrow: int) -> Tensor:
+    """csrc/pipeline_kernels.hip::k_wgrad_rows: (D,H,W,C) -> (n_taps, C, lrow) channel-major rows over the convolution's output grid."""
+    import ctypes
     from ctypes import c_void_p
     from . import _lib
     d, h, w, c = x.shape
     out = torch.empty((n_taps, c, lrow), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().ndet_wgrad_rows(c_void_p(x.data_ptr()), d, h, w, c, k3[0], k3[1], k3[2], pads[0], pads[1], pads[2], t0, n_taps, margin,
-                                           lrow, c_void_p(out.data_ptr()), c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "wgrad_rows")
+    i3 = lambda v: (ctypes.c_int * 3)(*v)
+    _lib.check(_lib.load().ndet_wgrad_rows(c_void_p(x.data_ptr()), d, h, w, c, i3(k3), i3(stride3), i3(pads), t0, n_taps, lrow,
+                                           c_void_p(out.data_ptr()), c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "wgrad_rows")
     return out
 
 
-def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int]) -> Tensor:
-    """dW of a stride-1 same-padded convolution.  x (D,H,W,Cin), g (D,H,W,Cout) contiguous fp32 channels-last (2D: D = batch, kernel
-    (kh,kw)) -> (Cout, Cin, *kernel) in torch's layout."""
-    k3 = (1,) + tuple(kernel) if len(kernel) == 2 else tuple(kernel)
+def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pads=None) -> Tensor:
+    """dW of a convolution of uniform stride (same-padded unless ``pads`` says otherwise).  x (D,H,W,Cin), g (OD,OH,OW,Cout) contiguous fp32
+    channels-last (2D: D = batch, kernel (kh,kw)) -> (Cout, Cin, *kernel) in torch's layout."""
+    two_d = len(kernel) == 2
+    k3 = (1,) + tuple(kernel) if two_d else tuple(kernel)
+    s3 = (1, stride, stride) if two_d else (stride,) * 3
     d, h, w, cin = x.shape
     cout = g.shape[3]
-    pads = tuple(v // 2 for v in k3)
-    hp, wp = h + 2 * pads[1], w + 2 * pads[2]
-    lp = (d + 2 * pads[0]) * hp * wp
-    margin = pads[0] * hp * wp + pads[1] * wp + pads[2]     # largest |tap shift| of the flattened index
-    lrow = ((lp + 2 * margin + 31) // 32) * 32              # the kernel steps the contraction by 32
+    pads = tuple(v // 2 for v in k3) if pads is None else ((0,) + tuple(pads) if two_d else tuple(pads))
+    assert tuple(g.shape[:3]) == tuple((n + 2 * p - k) // s + 1 for n, p, k, s in zip((d, h, w), pads, k3, s3)), (tuple(x.shape), tuple(g.shape))
+    lo = g.shape[0] * g.shape[1] * g.shape[2]
+    lrow = ((lo + 31) // 32) * 32                           # the kernel steps the contraction by 32; the tail is staged as zeros
     taps = k3[0] * k3[1] * k3[2]
-    # dy as the GEMM's "weight" operand (Cout rows over the padded grid, zeros in halo and margins), split into bf16 planes once
-    grows = _rows(g, (1, 1, 1), pads, 0, 1, margin, lrow)
+    # dy as the GEMM's "weight" operand (Cout rows over the output grid), split into bf16 planes once
+    grows = _rows(g, (1, 1, 1), (1, 1, 1), (0, 0, 0), 0, 1, lrow)
     pk = dict(w=grows, scale=None, shift=None, cout=cout, cin=lrow, ksize=1, stride=1, transposed=False, kernel=(1, 1), strides=(1, 1),
               pads=(0, 0), ndim=2)
     per = max(1, min(taps, (1 << 30) // (cin * lrow * 4)))  # the kernel addresses its operand with 32-bit byte offsets: <= 1 GiB per launch
     parts = []
     for t0 in range(0, taps, per):
-        a_all = _rows(x, k3, pads, t0, min(per, taps - t0), margin, lrow)      # rows (t, ci): x shifted by tap t
-        parts.append(C.linear_rows(a_all.view(-1, lrow), pk))                  # (taps*Cin, Cout): the sum over the padded voxels
+        a_all = _rows(x, k3, s3, pads, t0, min(per, taps - t0), lrow)          # rows (t, ci): x sampled at tap t of every output voxel
+        parts.append(C.linear_rows(a_all.view(-1, lrow), pk))                  # (taps*Cin, Cout): the sum over the output voxels
     dw = parts[0] if len(parts) == 1 else torch.cat(parts)
     return dw.view(taps, cin, cout).permute(2, 1, 0).reshape(cout, cin, *kernel)
+
+
+def _dgrad_library(g: Tensor, x: Tensor, w: Tensor, stride: int) -> Tensor:
+    """Data gradient of a strided convolution through ATen (channels-last memory in and out): g (OD,OH,OW,Cout) / (N,OH,OW,Cout)."""
+    nd = w.dim() - 2
+    if nd == 3:
+        gl, xl = g.permute(3, 0, 1, 2).unsqueeze(0), x.permute(3, 0, 1, 2).unsqueeze(0)
+    else:
+        gl, xl = g.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2)
+    pad = [int(v) // 2 for v in w.shape[2:]]
+    dx = torch.ops.aten.convolution_backward(gl, xl, w, None, [stride] * nd, pad, [1] * nd, False, [0] * nd, 1, [True, False, False])[0]
+    dx = dx[0].permute(1, 2, 3, 0) if nd == 3 else dx.permute(0, 2, 3, 1)
+    return dx.contiguous()
 
 
 class ConvS1(torch.autograd.Function):
     """y = conv(x, weight) for channels-last x (D,H,W,Cin) / (N,H,W,Cin) and a torch-layout weight; see the module docstring."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, stride=1):
         kernel = tuple(weight.shape[2:])
-        ctx.kernel = kernel
+        ctx.kernel, ctx.stride = kernel, int(stride)
         w = weight.detach()
         ctx.save_for_backward(x.detach(), w)
-        return _conv(x.detach().contiguous(), _train_pack(w, kernel, False))
+        return _conv(x.detach().contiguous(), _train_pack(w, kernel, False, int(stride)))
 
     @staticmethod
     def backward(ctx, g):
@@ -131,18 +148,60 @@ class ConvS1(torch.autograd.Function):
         g = g.contiguous().float()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            # the adjoint convolution: W'[ci, co, t] = W[co, ci, flip(t)]; the kernel steps its input channels by 32, so dy (and W')
-            # are zero-padded when Cout is not a multiple
-            gd = g if g.shape[-1] % 32 == 0 else torch.nn.functional.pad(g, (0, 32 - g.shape[-1] % 32))
-            dx = _conv(gd, _train_pack(w, ctx.kernel, True))
+            if ctx.stride == 1:
+                # the adjoint convolution: W'[ci, co, t] = W[co, ci, flip(t)]; the kernel steps its input channels by 32, so dy (and W')
+                # are zero-padded when Cout is not a multiple
+                gd = g if g.shape[-1] % 32 == 0 else torch.nn.functional.pad(g, (0, 32 - g.shape[-1] % 32))
+                dx = _conv(gd, _train_pack(w, ctx.kernel, True))
+            else:
+                dx = _dgrad_library(g, x, w, ctx.stride)
         if ctx.needs_input_grad[1]:
-            dw = weight_grad(x, g, ctx.kernel)
+            dw = weight_grad(x, g, ctx.kernel, ctx.stride)
+        return dx, dw, None
+
+
+class ConvT2(torch.autograd.Function):
+    """y = ConvTranspose3d(k = 2, s = 2)(x) for channels-last x (D,H,W,Cin) and the torch-layout weight (Cin, Cout, 2,2,2) -- the up-blocks
+    of mmdet3d/models/necks/imvoxelnet.py:233-260.  Forward: the transposed form of the inference kernel (each input voxel writes its
+    2x2x2 block).  The data gradient is the stride-2, unpadded 2x2x2 CONVOLUTION of dy with the very same tensor read as a Conv3d weight
+    (out = Cin, in = Cout, no flip); the weight gradient is that convolution's weight gradient with the roles of x and dy swapped."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        w = weight.detach()
+        ctx.save_for_backward(x.detach(), w)
+        pk = dict(w=C.pack_weight(w, True), scale=None, shift=None, cout=int(w.shape[1]), cin=int(w.shape[0]), ksize=2, stride=2, transposed=True,
+                  kernel=(2, 2, 2), strides=(2, 2, 2), pads=(0, 0, 0), ndim=3)
+        return C.conv3d_ndhwc(x.detach().contiguous(), pk)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous().float()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv(g, _train_pack(w, (2, 2, 2), False, 2, (0, 0, 0)))
+        if ctx.needs_input_grad[1]:
+            dw = weight_grad(g, x, (2, 2, 2), 2, (0, 0, 0))
         return dx, dw
+
+
+def eligible_transposed(conv: nn.Module, x: Tensor) -> bool:
+    return (isinstance(conv, nn.ConvTranspose3d) and C.ARITHMETIC in ("bf16x3", "bf16") and x.is_cuda and x.dtype == torch.float32 and tuple(conv.kernel_size) == (2, 2, 2)
+            and tuple(conv.stride) == (2, 2, 2) and tuple(conv.padding) == (0, 0, 0) and tuple(conv.output_padding) == (0, 0, 0)
+            and tuple(conv.dilation) == (1, 1, 1) and conv.groups == 1 and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0)
 
 
 def conv_forward(conv: nn.Module, x: Tensor) -> Tensor:
     """``conv(x)`` for a logical (B,C,...) tensor: eligible layers run on the MFMA kernels under autograd (channels-last memory in,
     channels-last memory out, logical shape unchanged); everything else goes to the module itself."""
+    if torch.is_grad_enabled() and eligible_transposed(conv, x):
+        outs = []
+        for b in range(x.shape[0]):
+            xb = x[b].permute(1, 2, 3, 0)
+            outs.append(ConvT2.apply(xb if xb.is_contiguous() else xb.contiguous(), conv.weight).permute(3, 0, 1, 2))
+        y = outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
+        return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1, 1)
     if not (torch.is_grad_enabled() and eligible(conv, x)):
         return conv(x)
     three_d = isinstance(conv, nn.Conv3d)
@@ -150,12 +209,12 @@ def conv_forward(conv: nn.Module, x: Tensor) -> Tensor:
     if three_d:
         for b in range(x.shape[0]):                                           # one scene at a time: the kernel's depth axis is X
             xb = x[b].permute(1, 2, 3, 0)
-            y = ConvS1.apply(xb if xb.is_contiguous() else xb.contiguous(), conv.weight)
+            y = ConvS1.apply(xb if xb.is_contiguous() else xb.contiguous(), conv.weight, conv.stride[0])
             outs.append(y.permute(3, 0, 1, 2))
         y = outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
     else:
         xb = x.permute(0, 2, 3, 1)
-        y = ConvS1.apply(xb if xb.is_contiguous() else xb.contiguous(), conv.weight).permute(0, 3, 1, 2)
+        y = ConvS1.apply(xb if xb.is_contiguous() else xb.contiguous(), conv.weight, conv.stride[0]).permute(0, 3, 1, 2)
     if conv.bias is not None:
         y = y + conv.bias.view(1, -1, *([1] * (y.dim() - 2)))
     return y
@@ -165,7 +224,7 @@ def conv_forward_shared(convs: Sequence[nn.Module], x: Tensor):
     """Several convolutions reading the same input (the head's centerness / regression / class layers,
     mmdet3d/models/dense_heads/imvoxel_head_v2.py:444-449) as ONE convolution over their concatenated output channels -- one forward,
     one data gradient and one weight gradient launch instead of three each.  Returns the per-layer outputs (biases added)."""
-    if not (torch.is_grad_enabled() and all(eligible(c, x) for c in convs) and len({tuple(c.kernel_size) for c in convs}) == 1):
+    if not (torch.is_grad_enabled() and all(eligible(c, x) and c.stride[0] == 1 for c in convs) and len({tuple(c.kernel_size) for c in convs}) == 1):
         return [c(x) for c in convs]
     w = torch.cat([c.weight for c in convs], dim=0)
     outs = []

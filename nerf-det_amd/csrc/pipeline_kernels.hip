@@ -106,29 +106,28 @@ extern "C" int ndet_target_rays(const uint8_t* frames_bgr, const int* target_ids
 }
 
 // ------------------------------------------------------------------------------------------------
-// Weight-gradient staging (nerfdet_amd/conv_train.py): channels-last activations (D,H,W,C) -> channel-major rows over the
-// zero-padded, flattened grid, one copy per tap shifted by the tap's offset:
-//     out[t][c][j] = xpad[c][j + off(t) - margin]      (0 outside the grid's interior)
-// so that dW[t] = dY_rows . out[t]^T is a plain GEMM over j (autograd of nn.Conv3d / nn.Conv2d in
-// mmdet3d/models/necks/imvoxelnet.py:22-67,233-260).  Every destination element is written exactly once (halo and margins as
-// zeros): no separate clear.  64 positions x 64 channels per workgroup through an LDS transpose: reads coalesced along C, writes
-// coalesced along j.
+// Weight-gradient staging (nerfdet_amd/conv_train.py): channels-last activations (D,H,W,C) -> channel-major rows over the flattened
+// OUTPUT grid (OD,OH,OW) of the convolution, one copy per tap:
+//     out[t][c][j] = x[s * o(j) + tap(t) - pad][c]     (0 where that voxel lies outside the input, and for j past the grid)
+// so that dW[t] = dY_rows . out[t]^T is a plain GEMM over j for any stride (autograd of nn.Conv3d / nn.Conv2d in
+// mmdet3d/models/necks/imvoxelnet.py:22-67,233-260).  dY itself is staged by the same kernel (1x1x1 tap, stride 1: a transpose).
+// Every destination element is written exactly once: no separate clear.  64 positions x 64 channels per workgroup through an LDS
+// transpose: reads coalesced along C, writes coalesced along j.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_wgrad_rows(const float* __restrict__ x, int D, int H, int W, int C, int kd, int kh, int kw, int pd,
-                                                    int ph, int pw, int t0, int margin, int lrow, float* __restrict__ out) {
+                                                    int ph, int pw, int sd, int sh, int sw, int OD, int OH, int OW, int t0, int lrow,
+                                                    float* __restrict__ out) {
     __shared__ float tile[64][65];
-    __shared__ int src[64];                                  // source voxel of each of the 64 positions, -1 = halo / margin
+    __shared__ int src[64];                                  // source voxel of each of the 64 positions, -1 = padding / past the grid
     const int j0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int t = t0 + blockIdx.z;
-    const int Hp = H + 2 * ph, Wp = W + 2 * pw;
     const int a = t / (kh * kw), b = (t / kw) % kh, c = t % kw;
-    const int off = (a - kd / 2) * Hp * Wp + (b - kh / 2) * Wp + (c - kw / 2);
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    if (threadIdx.x < 64) {                                  // one index decode per position (three integer divisions), not per element
-        const int vp = j0 + tx + off - margin;               // index in the padded grid
+    if (threadIdx.x < 64) {                                  // one index decode per position (integer divisions), not per element
+        const int j = j0 + tx;
         int s_ = -1;
-        if (vp >= 0) {
-            const int w_ = vp % Wp - pw, h_ = (vp / Wp) % Hp - ph, d_ = vp / (Wp * Hp) - pd;
+        if (j < OD * OH * OW) {
+            const int w_ = (j % OW) * sw + c - pw, h_ = ((j / OW) % OH) * sh + b - ph, d_ = (j / (OW * OH)) * sd + a - pd;
             if (w_ >= 0 && w_ < W && h_ >= 0 && h_ < H && d_ >= 0 && d_ < D) s_ = (d_ * H + h_) * W + w_;
         }
         src[tx] = s_;
@@ -149,17 +148,21 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(const float* __restrict__ x,
     }
 }
 
-extern "C" int ndet_wgrad_rows(const float* x_ndhwc, int D, int H, int W, int C, int kd, int kh, int kw, int pd, int ph, int pw, int t0,
-                               int n_taps, int margin, int lrow, float* out, void* stream) {
+extern "C" int ndet_wgrad_rows(const float* x_ndhwc, int D, int H, int W, int C, const int* kernel, const int* stride, const int* pad, int t0,
+                               int n_taps, int lrow, float* out, void* stream) {
     const char* fn = "ndet_wgrad_rows";
-    NDET_REQUIRE(x_ndhwc && out, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(x_ndhwc && out && kernel && stride && pad, NDET_E_INVALID, "%s: null pointer", fn);
+    const int kd = kernel[0], kh = kernel[1], kw = kernel[2];
     NDET_REQUIRE(D > 0 && H > 0 && W > 0 && C > 0 && kd > 0 && kh > 0 && kw > 0 && n_taps > 0 && t0 >= 0 && t0 + n_taps <= kd * kh * kw && lrow > 0,
                  NDET_E_INVALID, "%s: bad sizes", fn);
-    NDET_REQUIRE((int64_t)(D + 2 * pd) * (H + 2 * ph) * (W + 2 * pw) + 2 * (int64_t)margin <= lrow && margin >= 0, NDET_E_INVALID,
-                 "%s: row shorter than the padded grid plus its margins", fn);
+    for (int a = 0; a < 3; ++a)
+        NDET_REQUIRE(stride[a] >= 1 && pad[a] >= 0 && pad[a] < kernel[a], NDET_E_INVALID, "%s: bad stride / pad on axis %d", fn, a);
+    const int OD = (D + 2 * pad[0] - kd) / stride[0] + 1, OH = (H + 2 * pad[1] - kh) / stride[1] + 1, OW = (W + 2 * pad[2] - kw) / stride[2] + 1;
+    NDET_REQUIRE(OD > 0 && OH > 0 && OW > 0 && (int64_t)OD * OH * OW <= lrow && (int64_t)D * H * W < ((int64_t)1 << 31), NDET_E_INVALID,
+                 "%s: row shorter than the output grid (%d x %d x %d)", fn, OD, OH, OW);
     NDET_REQUIRE((C + 63) / 64 <= 65535 && n_taps <= 65535, NDET_E_UNSUPPORTED, "%s: grid too large", fn);
     hipLaunchKernelGGL(k_wgrad_rows, dim3((lrow + 63) / 64, (C + 63) / 64, n_taps), dim3(256), 0, (hipStream_t)stream, x_ndhwc, D, H, W, C, kd, kh,
-                       kw, pd, ph, pw, t0, margin, lrow, out);
+                       kw, pad[0], pad[1], pad[2], stride[0], stride[1], stride[2], OD, OH, OW, t0, lrow, out);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }

@@ -26,7 +26,9 @@ class BaseDetector(nn.Module):
         return self.forward_test(img, img_metas, **kwargs)
 
     @staticmethod
-    def _parse_losses(losses):
+    def _parse_losses(losses, defer_log=False):
+        """mmdet's BaseDetector._parse_losses.  ``defer_log``: the logged values stay device scalars (the caller reads them after it has
+        queued backward and the optimizer step -- ``.item()`` here drains the launch queue between forward and backward)."""
         import torch.distributed as dist
         log = {}
         for k, v in losses.items():
@@ -38,11 +40,11 @@ class BaseDetector(nn.Module):
             v = v.detach().clone()
             if dist.is_available() and dist.is_initialized():
                 dist.all_reduce(v.div_(dist.get_world_size()))
-            out[k] = v.item()
+            out[k] = v if defer_log else v.item()
         return loss, out
 
-    def train_step(self, data, optimizer=None):
-        loss, log_vars = self._parse_losses(self(**data))
+    def train_step(self, data, optimizer=None, defer_log=False):
+        loss, log_vars = self._parse_losses(self(**data), defer_log)
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data["img_metas"]))
 
 
@@ -112,8 +114,15 @@ class nerfdet(BaseDetector):
         assert ray_batch is not None and self.nerf_density and self.nerf_mode == "image", \
             "effective contract of the reference: use_ray=True, nerf_density=True, nerf_mode='image' (SURVEY.md 0.2)"
         trace.mark("begin")
+        begun = None
+        if mode == "train":
+            from .rays import begin_selection, finish_selection
+            begun = begin_selection(ray_batch)       # needs one host sync: taken before anything is queued
         x, batch, stride = self.extract_2d(img)
         trace.mark("backbone_fpn")
+        # the reference's host-side ray draw (a numpy permutation of every ray with depth: milliseconds) runs while the GPU works through
+        # the backbone queue; one draw per scene, in scene order, as render_ray.py:398 consumes its RandomState
+        picks = [finish_selection(begun, self.N_rand) for _ in img_metas] if begun is not None else None
         # per-scene constants: host arithmetic while the GPU works through the backbone queue, asynchronous upload
         geoms = None
         if not torch.is_grad_enabled():
@@ -133,7 +142,7 @@ class nerfdet(BaseDetector):
                 rgb_preds.append(render_rays(ray_batch, None, None, out["feature_2d"], dn, self.aabb, self.near_far_range,
                                              self.N_samples, self.N_rand, self.nerf_mlp, img_meta, None, self.nerf_mode,
                                              self.nerf_sample_view, is_train=(mode == "train"),
-                                             render_testing=self.render_testing))
+                                             render_testing=self.render_testing, selection=None if picks is None else picks[b]))
             else:
                 rgb_preds.append(None)  # render_ray.py:518-519
             volumes.append(out["volume"])

@@ -302,6 +302,8 @@ class ScanNetImVoxelHeadV2(nn.Module):
         val = torch.cat([v.permute(1, 2, 3, 0).reshape(-1) for v in valids])
         ctr_t, box_t, labels = ctr_t.to(dev), box_t.to(dev), labels.to(dev)
         pts = torch.cat(pts_l)
+        if ctr.is_cuda:
+            return self._losses_masked(ctr, reg, cls, val, pts, ctr_t, box_t, labels)
         pos = torch.nonzero(torch.logical_and(labels >= 0, val)).reshape(-1)
         n_pos = torch.tensor(len(pos), dtype=torch.float, device=dev)
         n_pos = max(_reduce_mean(n_pos), 1.0)
@@ -317,6 +319,28 @@ class ScanNetImVoxelHeadV2(nn.Module):
             loss_ctr, loss_box = ctr[pos].sum(), reg[pos].sum()
         return loss_ctr, loss_box, loss_cls
 
+    def _losses_masked(self, ctr, reg, cls, val, pts, ctr_t, box_t, labels):
+        """The three losses of imvoxel_head_v2.py:170-203 without reading anything back to the host: instead of gathering the positive /
+        valid locations (``nonzero``, ``len(pos)``, ``if torch.any``: each one a host sync in the middle of the step, after which the launch
+        queue is empty while the host builds the rest of the loss graph) every location is evaluated and weighted by its mask.  Row by row
+        the arithmetic is the reference's; only the order of the final sums differs.  Rows outside the mask get benign operands first (unit
+        boxes, target 0), so neither their values nor their gradients can turn into NaN x 0."""
+        from .losses import _reduce, aligned_iou_3d
+        posm = torch.logical_and(labels >= 0, val)
+        n_pos = torch.clamp(_reduce_mean(posm.sum().float()), min=1.0)
+        loss_cls = self.loss_cls(cls, labels, weight=val.to(cls.dtype), avg_factor=n_pos)
+        w_pos = posm.to(ctr.dtype)
+        loss_ctr = self.loss_centerness(ctr, torch.where(posm, ctr_t, torch.zeros_like(ctr_t)), weight=w_pos, avg_factor=n_pos)
+        pm = posm.unsqueeze(1)
+        unit = torch.ones_like(reg)
+        pred = _dist_to_box(pts, torch.where(pm, reg, unit))
+        target = torch.where(pm, box_t, _dist_to_box(pts, unit))
+        w_box = torch.where(posm, ctr_t, torch.zeros_like(ctr_t))
+        denom = w_box.sum()
+        denom = torch.where(denom > 0, denom, torch.ones_like(denom))           # no positives: the reference returns reg[pos].sum() = 0
+        loss_box = _reduce(1 - aligned_iou_3d(pred, target), w_box, "mean", denom) * self.loss_bbox.loss_weight
+        return loss_ctr, loss_box, loss_cls
+
     @torch.no_grad()
     def get_targets(self, points, gt_bboxes, gt_labels):
         """FCOS-3D assignment of imvoxel_head_v2.py:457-526: a location is positive for a box when it is
@@ -325,7 +349,7 @@ class ScanNetImVoxelHeadV2(nn.Module):
         locations; ties between boxes go to the smallest volume."""
         big = 1e8
         dev = gt_labels.device
-        lvl = torch.cat([p.new_tensor(i).expand(len(p)) for i, p in enumerate(points)]).to(dev)
+        lvl = torch.cat([torch.full((len(p),), float(i), dtype=p.dtype, device=p.device) for i, p in enumerate(points)]).to(dev)
         pts = torch.cat(points, dim=0).to(dev)
         n_pts, n_box = len(pts), len(gt_bboxes)
         vol = gt_bboxes.volume.to(dev).expand(n_pts, n_box).contiguous()
@@ -335,7 +359,7 @@ class ScanNetImVoxelHeadV2(nn.Module):
                          p[..., 1] - gt[..., 1] + gt[..., 4] / 2, gt[..., 1] + gt[..., 4] / 2 - p[..., 1],
                          p[..., 2] - gt[..., 2] + gt[..., 5] / 2, gt[..., 2] + gt[..., 5] / 2 - p[..., 2]), dim=-1)
         inside = t.min(-1)[0] > 0
-        per_scale = torch.stack([torch.sum(inside[lvl == i], dim=0) for i in range(self.n_scales)], dim=0)
+        per_scale = torch.stack([torch.sum(torch.logical_and(inside, (lvl == i).unsqueeze(1)), dim=0) for i in range(self.n_scales)], dim=0)
         low = per_scale < self.limit
         rank = torch.arange(self.n_scales, 0, -1, device=dev).unsqueeze(1).expand(self.n_scales, n_box)
         first_low = torch.argmax(low.int() * rank, dim=0) - 1
@@ -353,7 +377,7 @@ class ScanNetImVoxelHeadV2(nn.Module):
         min_vol, arg = vol.min(dim=1)
         labels = gt_labels[arg]
         labels = torch.where(min_vol == big, torch.ones_like(labels) * -1, labels)
-        t = t[range(n_pts), arg]
+        t = t[torch.arange(n_pts, device=dev), arg]
         return compute_centerness(t), _dist_to_box(pts, t), labels
 
 

@@ -29,7 +29,7 @@ def aligned_iou_3d(a, b, eps: float = 1e-6):
     vb = (b[..., 3] - b[..., 0]) * (b[..., 4] - b[..., 1]) * (b[..., 5] - b[..., 2])
     ext = (torch.min(a[..., 3:], b[..., 3:]) - torch.max(a[..., :3], b[..., :3])).clamp(min=0)
     inter = ext[..., 0] * ext[..., 1] * ext[..., 2]
-    union = torch.max(va + vb - inter, inter.new_tensor([eps]))
+    union = (va + vb - inter).clamp(min=eps)      # = max(., eps) without shipping a constant to the device
     return inter / union
 
 
@@ -61,7 +61,7 @@ class FocalLoss(nn.Module):
         n_cls = pred.shape[1]
         t = torch.zeros_like(pred)
         fg = (target >= 0) & (target < n_cls)
-        t[fg.nonzero(as_tuple=True)[0], target[fg]] = 1.0
+        t.scatter_(1, target.clamp(0, n_cls - 1).view(-1, 1), fg.to(pred.dtype).view(-1, 1))   # one-hot rows, nothing read back by the host
         p = pred.sigmoid()
         pt = (1 - p) * t + p * (1 - t)
         fw = (self.alpha * t + (1 - self.alpha) * (1 - t)) * pt.pow(self.gamma)

@@ -32,7 +32,7 @@ class BasicBlock3dV2(nn.Module):
         MFMA kernels, forward and backward (nerfdet_amd/conv_train.py)."""
         out = self.relu(self.norm1(conv_forward(self.conv1, x)))
         out = self.norm2(conv_forward(self.conv2, out))
-        idt = self.downsample(x) if self.stride != 1 else x
+        idt = _run(self.downsample, x) if self.stride != 1 else x
         return self.relu(out + idt)
 
     def forward_ndhwc(self, x):
@@ -47,9 +47,9 @@ def _conv_bn_relu(cin, cout):
 
 
 def _run(seq: nn.Sequential, x):
-    """``seq(x)`` with its stride-1 convolutions routed through :func:`conv_forward`."""
+    """``seq(x)`` with its convolutions routed through :func:`conv_forward`."""
     for m in seq:
-        x = conv_forward(m, x) if isinstance(m, nn.Conv3d) else m(x)
+        x = conv_forward(m, x) if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d)) else m(x)
     return x
 
 

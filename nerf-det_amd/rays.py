@@ -49,6 +49,14 @@ def _camera_matrices(train_cameras: Tensor) -> Tuple[Tensor, float, float]:
     return ke, float(cams[0, 0]), float(cams[0, 1])
 
 
+def _to_device(host: Tensor, device) -> Tensor:
+    """Small per-scene constants go up through the pinned staging ring of nerfdet_amd.ops: a pageable copy waits for everything queued."""
+    if torch.device(device).type != "cuda" or host.is_cuda:
+        return host.to(device)
+    from .ops import _upload_async
+    return _upload_async(host, device)
+
+
 def _prep_sources(train_imgs: Tensor, featmaps: Tensor):
     """train_imgs (1,n_v,H,W,3) as the reference passes it (a permuted view of the (n_v,3,H,W) images) or the
     (n_v,3,H,W) tensor itself; featmaps logical (n_v,d,h,w)."""
@@ -102,7 +110,7 @@ def ray_view_stats(xyz: Tensor, train_imgs: Tensor, train_cameras: Tensor, featm
         raise RuntimeError("nerfdet_amd.rays: tensors must live on the GPU (no CPU fallback)")
     cams = train_cameras.squeeze(0) if train_cameras.dim() == 3 else train_cameras
     ke, h, w = _camera_matrices(cams)
-    ke = ke.to(xyz.device)
+    ke = _to_device(ke, xyz.device)
     rgb, f = _prep_sources(train_imgs, featmaps)
     n_v, d, hf, wf = f.shape
     assert rgb.shape[0] == n_v and ke.shape[0] == n_v
@@ -141,7 +149,7 @@ class Projector:
         if not xyz.is_cuda:
             raise RuntimeError("nerfdet_amd.rays: tensors must live on the GPU (no CPU fallback)")
         ke, h, w = _camera_matrices(train_cameras.squeeze(0))
-        ke = ke.to(xyz.device)
+        ke = _to_device(ke, xyz.device)
         rgb, f = _prep_sources(train_imgs, featmaps)
         n_v, d, hf, wf = f.shape
         r, s = xyz.shape[:2]
@@ -247,22 +255,41 @@ def render_rays_func(ray_o, ray_d, mean_volume, cov_volume, features_2D, img, aa
     return ret
 
 
+def begin_selection(ray_batch):
+    """First half of the training-time ray draw of render_ray.py:386-404: the rays WITH depth (``gt_depth > 0``; all rays when the scene has
+    no depth maps), as indices into the flattened ray list, and their number.  Depends on the inputs only, so the detector takes it
+    before it queues the backbone: the one host sync it needs then waits for nothing."""
+    gt_depth = ray_batch["gt_depth"]
+    rays = ray_batch["ray_d"].view(-1, 3)
+    if len(gt_depth) == 0:
+        return None, rays.shape[0], rays.device
+    kept = torch.nonzero(gt_depth.view(-1) > 0).view(-1)
+    return kept, int(kept.numel()), rays.device
+
+
+def finish_selection(begun, n_rand):
+    """Second half: ``N_rand`` of those rays drawn without replacement from the module-global RandomState (the reference's stream and call,
+    render_ray.py:20,398 -- a permutation of all kept rays on the host, milliseconds: the detector runs it while the GPU works through
+    the backbone).  Returns indices into the flattened ray list (device tensor)."""
+    kept, n, dev = begun
+    draw = torch.from_numpy(rng.choice(n, size=(n_rand,), replace=False))
+    if torch.device(dev).type == "cuda":
+        from .ops import _upload_async
+        draw = _upload_async(draw, dev)           # pinned staging: a pageable copy here would wait for the queued backbone to drain
+    return draw if kept is None else kept[draw]
+
+
 def render_rays(ray_batch, mean_volume, cov_volume, features_2D, img, aabb, near_far_range, N_samples, N_rand=4096, nerf_mlp=None,
                 img_meta=None, projector=None, mode="volume", nerf_sample_view=3, inv_uniform=False, N_importance=0, det=False,
-                is_train=True, white_bkgd=False, render_testing=False):
+                is_train=True, white_bkgd=False, render_testing=False, selection=None):
     """render_ray.py:371-520: training = drop rays without depth, draw ``N_rand`` rays from the module-global
     RandomState, one ``render_rays_func``; ``render_testing`` = every ray of the target views in chunks of
     ``N_rand``, deterministic sampling; otherwise ``None``."""
     ray_o, ray_d, gt_rgb, gt_depth = ray_batch["ray_o"], ray_batch["ray_d"], ray_batch["gt_rgb"], ray_batch["gt_depth"]
     if is_train:
         ray_o, ray_d, gt_rgb = ray_o.view(-1, 3), ray_d.view(-1, 3), gt_rgb.view(-1, 3)
-        if len(gt_depth) != 0:
-            gt_depth = gt_depth.view(-1, 1)
-            keep = (gt_depth > 0).squeeze(-1)
-            ray_o, ray_d, gt_rgb, gt_depth = ray_o[keep], ray_d[keep], gt_rgb[keep], gt_depth[keep]
-        else:
-            gt_depth = None
-        sel = torch.from_numpy(rng.choice(ray_d.shape[0], size=(N_rand,), replace=False)).to(ray_d.device)
+        gt_depth = gt_depth.view(-1, 1) if len(gt_depth) != 0 else None
+        sel = selection if selection is not None else finish_selection(begin_selection(ray_batch), N_rand)
         ray_o, ray_d, gt_rgb = ray_o[sel], ray_d[sel], gt_rgb[sel]
         if gt_depth is not None:
             gt_depth = gt_depth[sel]

@@ -19,9 +19,9 @@ class DDPDetector(DistributedDataParallel):
     """``MMDistributedDataParallel`` as the runner uses it: ``train_step(data, optimizer)`` goes through DDP's forward (so the
     gradient hooks are armed) and returns ``dict(loss, log_vars, num_samples)`` like ``BaseDetector.train_step``."""
 
-    def train_step(self, data: Dict, optimizer=None):
+    def train_step(self, data: Dict, optimizer=None, defer_log=False):
         losses = self(**data)
-        loss, log_vars = self.module._parse_losses(losses)
+        loss, log_vars = self.module._parse_losses(losses, defer_log)
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data["img_metas"]))
 
 
@@ -52,11 +52,13 @@ def train_one_step(model, data: Dict, optimizer, grad_clip: float = 35.0) -> Dic
     """One iteration of the runner's loop: forward, backward (DDP all-reduces the gradients while it runs),
     clip (config:173), step."""
     optimizer.zero_grad(set_to_none=True)
-    out = model.train_step(data, optimizer)
+    out = model.train_step(data, optimizer, defer_log=True)     # logged scalars stay on the device until the whole step is queued
     out["loss"].backward()
     module = model.module if isinstance(model, DistributedDataParallel) else model
     params = [p for p in module.parameters() if p.requires_grad and p.grad is not None]
-    if grad_clip and params:
-        out["grad_norm"] = float(torch.nn.utils.clip_grad_norm_(params, grad_clip))
+    norm = torch.nn.utils.clip_grad_norm_(params, grad_clip) if grad_clip and params else None
     optimizer.step()
+    out["log_vars"] = {k: float(v) for k, v in out["log_vars"].items()}     # the step's only host sync after its first launches
+    if norm is not None:
+        out["grad_norm"] = float(norm)
     return out

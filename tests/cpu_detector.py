@@ -32,7 +32,7 @@ def _extract_volume(features, denorm_images, img_meta, n_voxels, voxel_size, map
 def _make_render_rays(rng_holder):
     def render_rays(ray_batch, mean_volume, cov_volume, features_2D, img, aabb, near_far_range, N_samples, N_rand=4096, nerf_mlp=None,
                     img_meta=None, projector=None, mode="volume", nerf_sample_view=3, inv_uniform=False, N_importance=0, det=False,
-                    is_train=True, white_bkgd=False, render_testing=False):
+                    is_train=True, white_bkgd=False, render_testing=False, selection=None):
         if not is_train:
             return None
         ro, rd, rgb, dep = O.select_training_rays(ray_batch, N_rand, rng_holder["rng"])
@@ -50,6 +50,8 @@ def oracle_backed_cpu_ops(seed: int = 234):
     import nerfdet_amd.rays as R
     holder = {"rng": np.random.RandomState(seed)}
     saved = (D.extract_volume, R.render_rays, H.ops.get_points)
+    saved_sel = (R.begin_selection, R.finish_selection)      # the oracle draws the rays itself (same RandomState protocol)
+    R.begin_selection, R.finish_selection = (lambda ray_batch: None), (lambda begun, n_rand: None)
 
     def get_points(n_voxels, voxel_size, origin, device=None):
         vs = voxel_size.tolist() if isinstance(voxel_size, torch.Tensor) else list(voxel_size)
@@ -59,3 +61,4 @@ def oracle_backed_cpu_ops(seed: int = 234):
         yield holder
     finally:
         D.extract_volume, R.render_rays, H.ops.get_points = saved
+        R.begin_selection, R.finish_selection = saved_sel

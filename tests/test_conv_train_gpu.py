@@ -1,5 +1,5 @@
 """Training-time convolutions on the MFMA kernels (nerfdet_amd/conv_train.py): forward, data gradient (the same kernel on the
-tap-flipped transposed weight) and weight gradient (one GEMM over the zero-padded flattened grid) against PyTorch-CPU fp32
+tap-flipped transposed weight) and weight gradient (one GEMM over the flattened output grid, any stride) against PyTorch-CPU fp32
 autograd of ``F.conv3d`` / ``F.conv2d`` -- the arithmetic mmdet3d/models/necks/imvoxelnet.py:22-67,233-260 runs in training."""
 import pytest
 import torch
@@ -12,24 +12,26 @@ def _rel(a, b):
     return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
 
 
-@pytest.mark.parametrize("dims,cin,cout,k", [((9, 7, 5), 64, 96, 3), ((6, 6, 4), 32, 32, 1), ((12, 10, 6), 128, 64, 3), ((8, 8, 4), 128, 25, 3),
-                                            ((3, 11, 13), 64, 32, (3, 3)), ((2, 8, 6), 96, 64, (1, 1)), ((5, 9, 9), 32, 64, (3, 3))])
-def test_conv_s1_forward_dgrad_wgrad_vs_torch_cpu(device, dims, cin, cout, k):
+@pytest.mark.parametrize("dims,cin,cout,k,stride", [((9, 7, 5), 64, 96, 3, 1), ((6, 6, 4), 32, 32, 1, 1), ((12, 10, 6), 128, 64, 3, 1), ((8, 8, 4), 128, 25, 3, 1),
+                                                   ((3, 11, 13), 64, 32, (3, 3), 1), ((2, 8, 6), 96, 64, (1, 1), 1), ((5, 9, 9), 32, 64, (3, 3), 1),
+                                                   ((9, 8, 6), 64, 128, 3, 2), ((8, 6, 4), 64, 96, 1, 2),            # the neck's stride-2 3x3x3 / 1x1x1 downsample layers
+                                                   ((3, 11, 14), 64, 64, (3, 3), 2), ((2, 9, 12), 128, 256, (1, 1), 2)])
+def test_conv_s1_forward_dgrad_wgrad_vs_torch_cpu(device, dims, cin, cout, k, stride):
     from nerfdet_amd.conv_train import ConvS1
     torch.manual_seed(sum(dims) + cin)
     two_d = isinstance(k, tuple)
     ks = k if two_d else (k,) * 3
     x = torch.randn(*dims, cin)                                    # channels-last: (D,H,W,C) or (N,H,W,C)
     w = torch.randn(cout, cin, *ks) / (cin * max(1, ks[0] * ks[-1])) ** 0.5
-    gy = torch.randn(*dims, cout)
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     if two_d:
-        ref = F.conv2d(xr.permute(0, 3, 1, 2), wr, padding=tuple(v // 2 for v in ks)).permute(0, 2, 3, 1)
+        ref = F.conv2d(xr.permute(0, 3, 1, 2), wr, stride=stride, padding=tuple(v // 2 for v in ks)).permute(0, 2, 3, 1)
     else:
-        ref = F.conv3d(xr.permute(3, 0, 1, 2).unsqueeze(0), wr, padding=k // 2)[0].permute(1, 2, 3, 0)
+        ref = F.conv3d(xr.permute(3, 0, 1, 2).unsqueeze(0), wr, stride=stride, padding=k // 2)[0].permute(1, 2, 3, 0)
+    gy = torch.randn(*ref.shape)
     (ref * gy).sum().backward()
     xg, wg = x.to(device).requires_grad_(True), w.to(device).requires_grad_(True)
-    out = ConvS1.apply(xg, wg)
+    out = ConvS1.apply(xg, wg, stride)
     (out * gy.to(device)).sum().backward()
     assert _rel(out.detach().cpu(), ref.detach()) <= 2e-5
     assert _rel(xg.grad.cpu(), xr.grad) <= 2e-5
@@ -104,3 +106,23 @@ def test_head_training_forward_shares_one_convolution(device):
     assert set(ours[2]) == set(exact[2]) and "cls_conv.bias" in ours[2] and "scales.1.scale" in ours[2]
     for n in exact[2]:
         assert _rel(ours[2][n], exact[2][n]) <= 5e-5, n
+
+
+@pytest.mark.parametrize("dims,cin,cout", [((5, 4, 3), 64, 32), ((6, 5, 2), 128, 64)])
+def test_conv_transposed_k2s2_forward_dgrad_wgrad_vs_torch_cpu(device, dims, cin, cout):
+    """ConvT2 (the neck's up-blocks, necks/imvoxelnet.py:233-260) against PyTorch-CPU fp32 autograd of F.conv_transpose3d."""
+    from nerfdet_amd.conv_train import ConvT2
+    torch.manual_seed(sum(dims) + cin)
+    x = torch.randn(*dims, cin)
+    w = torch.randn(cin, cout, 2, 2, 2) / cin ** 0.5
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv_transpose3d(xr.permute(3, 0, 1, 2).unsqueeze(0), wr, stride=2)[0].permute(1, 2, 3, 0)
+    gy = torch.randn(*ref.shape)
+    (ref * gy).sum().backward()
+    xg, wg = x.to(device).requires_grad_(True), w.to(device).requires_grad_(True)
+    out = ConvT2.apply(xg, wg)
+    (out * gy.to(device)).sum().backward()
+    assert out.shape == ref.shape
+    assert _rel(out.detach().cpu(), ref.detach()) <= 2e-5
+    assert _rel(xg.grad.cpu(), xr.grad) <= 2e-5
+    assert _rel(wg.grad.cpu(), wr.grad) <= 5e-5
