@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .conv3d import bn_relu_maxpool_nhwc, chain_ok, conv2d_chain_nhwc, conv2d_nhwc, packed
-from .conv_train import conv_forward
+from .conv_train import conv_bn_act, conv_forward
 from .registry import BACKBONES, NECKS
 
 
@@ -37,11 +37,10 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         # training on the GPU: the stride-1 convolutions run on the MFMA kernels, forward and backward (nerfdet_amd/conv_train.py)
-        idt = x if self.downsample is None else self.downsample[1](conv_forward(self.downsample[0], x))
-        out = F.relu(self.bn1(conv_forward(self.conv1, x)), inplace=True)
-        out = F.relu(self.bn2(conv_forward(self.conv2, out)), inplace=True)
-        out = self.bn3(conv_forward(self.conv3, out))
-        return F.relu(out + idt, inplace=True)
+        idt = x if self.downsample is None else conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
+        out = conv_bn_act(self.conv1, self.bn1, x)
+        out = conv_bn_act(self.conv2, self.bn2, out)
+        return conv_bn_act(self.conv3, self.bn3, out, relu=True, residual=idt)
 
     def forward_nhwc(self, x):
         """Inference form on (N,H,W,C): every conv carries its frozen BatchNorm, ReLU and (last one) the residual

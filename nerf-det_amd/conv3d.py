@@ -176,6 +176,17 @@ def fold_bn(bn, bias: Optional[torch.Tensor], cout: int, device):
     return alpha.contiguous(), beta.contiguous()
 
 
+def bn_affine(bn: nn.Module):
+    """(scale, shift) of an eval-mode BatchNorm, cached on the module until one of its tensors changes."""
+    store = bn.__dict__.setdefault("_ndet_packed", {})
+    stamp = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    hit = store.get("affine")
+    if hit is None or hit[0] != stamp:
+        hit = (stamp, fold_bn(bn, None, bn.num_features, bn.weight.device))
+        store["affine"] = hit
+    return hit[1]
+
+
 def packed(convs: Sequence[nn.Module], bn: Optional[nn.BatchNorm3d] = None):
     """Pack (and cache) one conv, or several convs sharing an input concatenated along Cout.  The cache entry is
     rebuilt when any parameter was updated in place (optimizer step, load_state_dict)."""
@@ -348,13 +359,7 @@ def bn_relu_maxpool_nhwc(x: torch.Tensor, bn: nn.BatchNorm2d) -> torch.Tensor:
     """x (N,H,W,C) contiguous -> MaxPool2d(3,2,1)(relu(bn_eval(x))) in one pass (ResNet stem tail)."""
     assert x.is_cuda and x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
     n, h, w, c = x.shape
-    store = bn.__dict__.setdefault("_ndet_packed", {})
-    stamp = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
-    hit = store.get("affine")
-    if hit is None or hit[0] != stamp:
-        hit = (stamp, fold_bn(bn, None, c, x.device))
-        store["affine"] = hit
-    scale, shift = hit[1]
+    scale, shift = bn_affine(bn)
     out = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
     st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     check(_lib.load().ndet_bn_relu_maxpool_nhwc(_ptr(x), _ptr(scale), _ptr(shift), n, h, w, c, _ptr(out), st), "bn_relu_maxpool_nhwc")

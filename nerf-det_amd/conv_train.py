@@ -160,6 +160,66 @@ class ConvS1(torch.autograd.Function):
         return dx, dw, None
 
 
+class ConvAffineAct(torch.autograd.Function):
+    """y = act(conv(x, W) * scale + shift (+ residual)) with a CONSTANT per-channel affine -- a convolution followed by an eval-mode
+    BatchNorm whose parameters are frozen (the ResNet of the configs: ``norm_eval=True``, ``norm_cfg.requires_grad=False``), ReLU and the
+    bottleneck's identity add -- as ONE launch of the inference kernel with its fused epilogue.  Backward: the ReLU mask and the affine
+    are one elementwise pass over dy (g' = dy [y > 0] * scale, the identity's gradient is dy [y > 0]); g' then goes through the data and
+    weight gradients of ConvS1.  Everything stays in channels-last memory: the library's BatchNorm backward hands its gradient back
+    in NCHW order, which cost a transposing copy per layer."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift, residual, relu, stride):
+        kernel = tuple(weight.shape[2:])
+        w = weight.detach()
+        pk = _train_pack(w, kernel, False, int(stride))
+        pk["scale"], pk["shift"] = scale, shift
+        res = None if residual is None else residual.detach().contiguous()
+        y = (C.conv3d_ndhwc if pk["ndim"] == 3 else C.conv2d_nhwc)(x.detach().contiguous(), pk, residual=res, relu=1 if relu else 0)
+        ctx.kernel, ctx.stride, ctx.relu, ctx.has_res = kernel, int(stride), bool(relu), residual is not None
+        ctx.save_for_backward(x.detach(), w, scale, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, scale, y = ctx.saved_tensors
+        g = g.contiguous().float()
+        if ctx.relu:
+            g = g * (y > 0)
+        d_res = g if (ctx.has_res and ctx.needs_input_grad[4]) else None
+        gs = g * scale
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if ctx.stride == 1:
+                gd = gs if gs.shape[-1] % 32 == 0 else torch.nn.functional.pad(gs, (0, 32 - gs.shape[-1] % 32))
+                dx = _conv(gd, _train_pack(w, ctx.kernel, True))
+            else:
+                dx = _dgrad_library(gs, x, w, ctx.stride)
+        if ctx.needs_input_grad[1]:
+            dw = weight_grad(x, gs, ctx.kernel, ctx.stride)
+        return dx, dw, None, None, d_res, None, None
+
+
+def frozen_eval_bn(bn: nn.Module) -> bool:
+    return (isinstance(bn, (nn.BatchNorm2d, nn.BatchNorm3d)) and not bn.training and bn.track_running_stats and bn.affine
+            and not bn.weight.requires_grad and not bn.bias.requires_grad)
+
+
+def conv_bn_act(conv: nn.Module, bn: nn.Module, x: Tensor, relu: bool = True, residual: Tensor = None) -> Tensor:
+    """``act(bn(conv(x)) + residual)`` for a logical (B,C,H,W) tensor.  With an eligible convolution and a frozen eval-mode BatchNorm the
+    whole expression is one launch (ConvAffineAct); anything else is evaluated op by op."""
+    if torch.is_grad_enabled() and isinstance(conv, nn.Conv2d) and conv.bias is None and eligible(conv, x) and frozen_eval_bn(bn):
+        scale, shift = C.bn_affine(bn)
+        xb = x.permute(0, 2, 3, 1)
+        rb = None if residual is None else residual.permute(0, 2, 3, 1)
+        y = ConvAffineAct.apply(xb if xb.is_contiguous() else xb.contiguous(), conv.weight, scale, shift, rb, relu, conv.stride[0])
+        return y.permute(0, 3, 1, 2)
+    y = bn(conv_forward(conv, x))
+    if residual is not None:
+        y = y + residual
+    return torch.nn.functional.relu(y, inplace=True) if relu else y
+
+
 class ConvT2(torch.autograd.Function):
     """y = ConvTranspose3d(k = 2, s = 2)(x) for channels-last x (D,H,W,Cin) and the torch-layout weight (Cin, Cout, 2,2,2) -- the up-blocks
     of mmdet3d/models/necks/imvoxelnet.py:233-260.  Forward: the transposed form of the inference kernel (each input voxel writes its

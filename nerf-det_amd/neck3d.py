@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import torch
 from torch import nn
+import torch.nn.functional as F
 
 from .conv3d import conv3d_ndhwc, packed, to_ndhwc
 from .conv_train import conv_forward
@@ -30,8 +31,8 @@ class BasicBlock3dV2(nn.Module):
     def forward(self, x):
         """Library form (training: BatchNorm on batch statistics, autograd).  On the GPU the stride-1 convolutions still run on the
         MFMA kernels, forward and backward (nerfdet_amd/conv_train.py)."""
-        out = self.relu(self.norm1(conv_forward(self.conv1, x)))
-        out = self.norm2(conv_forward(self.conv2, out))
+        out = self.relu(_bn(self.norm1, conv_forward(self.conv1, x)))
+        out = _bn(self.norm2, conv_forward(self.conv2, out))
         idt = _run(self.downsample, x) if self.stride != 1 else x
         return self.relu(out + idt)
 
@@ -42,6 +43,25 @@ class BasicBlock3dV2(nn.Module):
         return conv3d_ndhwc(y, packed([self.conv2], self.norm2), residual=idt, relu=1)
 
 
+def _bn(bn: nn.BatchNorm3d, x):
+    """``bn(x)`` for a logical (B,C,D,H,W) tensor held in channels-last memory, evaluated on its (voxels, C) row view: F.batch_norm's 2D form
+    reduces over the same elements per channel (same statistics, same running-average update), and neither it nor autograd's backward
+    leaves channels-last memory -- the 5D library path returns NCDHW memory, forward and backward, and every convolution after it then
+    starts with a transposing copy."""
+    rows = x.permute(0, 2, 3, 4, 1) if (x.is_cuda and x.dim() == 5) else None
+    if rows is None or not rows.is_contiguous():
+        return bn(x)
+    factor = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            factor = 1.0 / float(bn.num_batches_tracked)
+    training = bn.training or (bn.running_mean is None and bn.running_var is None)
+    y = F.batch_norm(rows.reshape(-1, x.shape[1]), bn.running_mean if (not bn.training or bn.track_running_stats) else None,
+                     bn.running_var if (not bn.training or bn.track_running_stats) else None, bn.weight, bn.bias, training, factor, bn.eps)
+    return y.view(rows.shape).permute(0, 4, 1, 2, 3)
+
+
 def _conv_bn_relu(cin, cout):
     return nn.Sequential(nn.Conv3d(cin, cout, 3, 1, 1, bias=False), nn.BatchNorm3d(cout), nn.ReLU(inplace=True))
 
@@ -49,7 +69,7 @@ def _conv_bn_relu(cin, cout):
 def _run(seq: nn.Sequential, x):
     """``seq(x)`` with its convolutions routed through :func:`conv_forward`."""
     for m in seq:
-        x = conv_forward(m, x) if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d)) else m(x)
+        x = conv_forward(m, x) if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d)) else _bn(m, x) if isinstance(m, nn.BatchNorm3d) else m(x)
     return x
 
 

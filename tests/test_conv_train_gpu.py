@@ -126,3 +126,35 @@ def test_conv_transposed_k2s2_forward_dgrad_wgrad_vs_torch_cpu(device, dims, cin
     assert _rel(out.detach().cpu(), ref.detach()) <= 2e-5
     assert _rel(xg.grad.cpu(), xr.grad) <= 2e-5
     assert _rel(wg.grad.cpu(), wr.grad) <= 5e-5
+
+
+def test_bottleneck_training_forward_backward_vs_fp64(device):
+    """A ResNet bottleneck with frozen eval-mode BatchNorm in training (conv -> affine -> ReLU (+ identity) as single launches,
+    nerfdet_amd/conv_train.py::ConvAffineAct; stride-2 3x3 and the 1x1 stride-2 downsample included) against an fp64 CPU evaluation
+    of the same module: output, input gradient, weight gradients."""
+    import copy
+    from nerfdet_amd.backbone import Bottleneck
+    from torch import nn
+    torch.manual_seed(3)
+    ds = nn.Sequential(nn.Conv2d(128, 256, 1, 2, bias=False), nn.BatchNorm2d(256))
+    blk = Bottleneck(128, 64, stride=2, downsample=ds)
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 2.0); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+                m.weight.requires_grad_(False); m.bias.requires_grad_(False)
+    blk.eval()                                   # norm_eval=True: BatchNorm on running statistics while the weights train
+    x = torch.randn(3, 128, 14, 18)
+    gy = torch.randn(3, 256, 7, 9)
+
+    def run(mod, inp, g):
+        inp = inp.clone().requires_grad_(True)
+        out = mod(inp)
+        (out * g).sum().backward()
+        return out.detach().double().cpu(), inp.grad.double().cpu(), {n: p.grad.double().cpu() for n, p in mod.named_parameters() if p.grad is not None}
+    exact = run(copy.deepcopy(blk).double(), x.double(), gy.double())
+    ours = run(copy.deepcopy(blk).to(device), x.to(device).contiguous(memory_format=torch.channels_last), gy.to(device))
+    assert set(ours[2]) == set(exact[2]) and len(exact[2]) == 4
+    assert _rel(ours[0], exact[0]) <= 2e-5 and _rel(ours[1], exact[1]) <= 2e-5
+    for n in exact[2]:
+        assert _rel(ours[2][n], exact[2][n]) <= 5e-5, n
