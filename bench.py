@@ -63,6 +63,13 @@ def k2_algorithmic_bytes(w, cm=32):
     return 4 * (w["n_views"] * 3 * h * wd + w["n_views"] * cm * (h // 4) * (wd // 4) + 2 * (3 + cm) * n)
 
 
+def traffic_of(traffic, name):
+    """Per-launch bytes of kernel ``name`` ("k_conv_split_halo<4,4>") in a {profile kernel name: bytes} table; the profile's names carry
+    every template argument ("k_conv_split_halo<4,4,0>"), so the match is on the name up to its closing bracket."""
+    stem = name[:-1] if name.endswith(">") else name
+    return next((v for k, v in traffic.items() if k == name or k.startswith(stem + ",") or k.startswith(stem + "<") or k.startswith(stem + ">")), None)
+
+
 def measured_traffic(workload):
     """HBM-side bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE in separate
     passes, FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes): {kernel-name prefix: bytes}, source file."""
@@ -314,6 +321,7 @@ def main():
         spans = rec.span_ms()
         stages = rec.stage_ms()
         traffic, traffic_src = measured_traffic(args.workload)
+        conv_traffic = lambda name: traffic_of(traffic, name)
         bf16x3 = C3.ARITHMETIC == "bf16x3"
         if C3.ARITHMETIC == "bf16":
             conv_kernel = ("k_conv_split in its one-product mode (implicit-GEMM convolution, both operands rounded to bf16, one bf16 MFMA product per "
@@ -349,7 +357,7 @@ def main():
                 return None
             avg = sum(ms) / len(ms)
             ach = abytes / (avg * 1e-3) / 1e9
-            tr = next((v for k, v in traffic.items() if k.startswith(name)), None)   # profile names carry template arguments
+            tr = traffic_of(traffic, name)   # profile names carry template arguments
             return {"kernel": label, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": tr, "traffic_source": None if tr is None else
                     f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
@@ -377,8 +385,8 @@ def main():
             "roofline": {"kernel": f"{dom_name} (the convolution instantiation with the largest share of the step; event spans include the "
                                    f"split-K reduce launch where a layer splits K)",
                          "bound": "mfma", "achieved": dom_tflops, "peak": conv_peak, "unit": "TFLOP/s",
-                         "frac": dom_tflops / conv_peak, "traffic": traffic.get(dom_name),
-                         "traffic_source": None if traffic.get(dom_name) is None else traffic_src, "peak_note": conv_peak_note,
+                         "frac": dom_tflops / conv_peak, "traffic": conv_traffic(dom_name),
+                         "traffic_source": None if conv_traffic(dom_name) is None else traffic_src, "peak_note": conv_peak_note,
                          "algorithmic_flops_per_launch": dom_flops / dom_n, "algorithmic_bytes_per_launch": dom_bytes / dom_n,
                          "launches_per_step": dom_n / n_conv_steps,
                          "avg_launch_ms": dom_ms / dom_n, "total_ms_per_step": dom_ms / n_conv_steps, "sampled_steps": n_conv_steps},

@@ -45,6 +45,10 @@ def test_bench_bookkeeping():
     assert bench.k2_algorithmic_bytes(w) == 4 * (50 * 3 * 240 * 320 + 50 * 32 * 60 * 80 + 70 * 25600) == 83968000
     traffic, src = bench.measured_traffic("cfg2")
     assert traffic["k_backproject_aggregate"] > bench.k1_algorithmic_bytes(w) and src.startswith("profiles/")
+    # the bench names kernels without the trailing template arguments the profile carries: the dominant convolution must be found
+    assert bench.traffic_of(traffic, "k_conv_split_halo<4,4>") > 0 and bench.traffic_of(traffic, "k_density_features_packed") > 0
+    assert bench.traffic_of({"k_conv_split_halo<4,4,0>": 7, "k_conv_split_halo<4,2,0>": 9}, "k_conv_split_halo<4,2>") == 9
+    assert bench.traffic_of({"k_conv_split<64,64,2,2,false>": 5}, "k_conv_split<64,64,2,2>") == 5 and bench.traffic_of({}, "k_x") is None
     # BASELINE.json configs[4] as stated: ResNet-101, 101 views 320x480, 80x80x32 voxels
     w5 = bench.WORKLOADS["cfg5"]
     assert (w5["n_views"], w5["img_hw"], w5["n_voxels"], w5["depth"]) == (101, (320, 480), (80, 80, 32), 101)
