@@ -173,3 +173,43 @@ def test_head_loss_at_cfg2_size_matches_oracle(device):
     got.sum().backward()
     for a, r in zip(ctr_g + reg_g + cls_g, ref_grads):
         torch.testing.assert_close(a.grad.cpu(), r, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_head_loss_without_positives_is_zero_with_finite_gradients(device):
+    """No location inside any box (imvoxel_head_v2.py:196-199 returns ``pred[pos].sum()`` = 0 for the centerness and box terms): the
+    masked GPU form gives exact zeros there, the classification term equals the CPU (gathered, reference-structured) form, and no
+    gradient is NaN -- the rows outside the mask are evaluated on benign operands, not multiplied out after the fact."""
+    from nerfdet_amd.boxes import DepthInstance3DBoxes
+    from nerfdet_amd.config import ConfigDict
+    from nerfdet_amd.head import ScanNetImVoxelHeadV2
+    torch.manual_seed(5)
+    grid, vs, origin = (16, 16, 8), (0.16, 0.16, 0.2), np.array([0.0, 0.0, 0.5], dtype=np.float32)
+    head = ScanNetImVoxelHeadV2(n_classes=18, n_channels=8, n_reg_outs=6, n_scales=3, limit=27, centerness_topk=18,
+                                test_cfg=ConfigDict(nms_pre=1000, iou_thr=0.25, score_thr=0.01))
+    head.voxel_size = vs
+    far = torch.tensor([[50.0, 50.0, 50.0, 0.5, 0.5, 0.5, 0.0], [-40.0, 3.0, 1.0, 0.3, 0.3, 0.3, 0.0]])
+    labels = torch.tensor([3, 7])
+    sizes = [tuple(s // 2 ** i for s in grid) for i in range(3)]
+    ctr = [torch.randn(1, 1, *s) for s in sizes]
+    reg = [torch.randn(1, 6, *s) * 3 for s in sizes]          # negative distances included: degenerate boxes on unmasked rows would be NaN
+    cls = [torch.randn(1, 18, *s) for s in sizes]
+    valid = (torch.rand(1, 1, *grid) < 0.5).float()
+    meta = [dict(lidar2img=dict(origin=origin))]
+
+    def run(dev):
+        h = head.to(dev)
+        leaves = [t.clone().to(dev).requires_grad_() for t in ctr + reg + cls]
+        c, r, k = leaves[:3], leaves[3:6], leaves[6:]
+        tot = h.loss(c, r, k, valid.to(dev), meta, [DepthInstance3DBoxes(far.to(dev), box_dim=7, with_yaw=False, origin=(0.5, 0.5, 0.5))], [labels.to(dev)])
+        sum(tot.values()).backward()
+        return {n: float(v) for n, v in tot.items()}, [t.grad.cpu() for t in leaves]
+    from cpu_detector import oracle_backed_cpu_ops
+    got, g_gpu = run(device)
+    with oracle_backed_cpu_ops():                      # the package has no CPU lattice kernel: the oracle's stands in
+        ref, g_cpu = run("cpu")
+    assert got["loss_centerness"] == 0.0 and got["loss_bbox"] == 0.0 and ref["loss_centerness"] == 0.0 and ref["loss_bbox"] == 0.0
+    assert abs(got["loss_cls"] - ref["loss_cls"]) <= 1e-5 * max(1.0, abs(ref["loss_cls"]))
+    for a, b in zip(g_gpu, g_cpu):
+        assert torch.isfinite(a).all()
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-7)
