@@ -328,6 +328,16 @@ int ndet_target_rays(const uint8_t* frames_bgr, const int* target_ids, int n_tar
 int ndet_wgrad_rows(const float* x_ndhwc, int D, int H, int W, int C, const int* kernel, const int* stride, const int* pad, int t0,
                     int n_taps, int lrow, float* out, void* stream);
 
+/* Weight gradient of a convolution as ONE implicit GEMM (autograd of nn.Conv3d / nn.Conv2d in
+ * mmdet3d/models/necks/imvoxelnet.py:22-67,233-260 and of the ResNet / FPN layers): dw_rows[(t, ci)][co] = sum over output voxels j of
+ * x[stride * o(j) + tap(t) - pad][ci] * dy[j][co].  x (D,H,W,Cin) channels-last fp32 is read in place (transposed on its way into
+ * LDS); dy arrives as the bf16 planes of its channel-major rows: ndet_wgrad_rows(dy, 1x1x1) -> (Cout, lrow), then
+ * ndet_split_weights_bf16x3 on that (1, Cout, lrow) "weight".  dw_rows (taps * Cin, Cout) row-major; Cin % 64 == 0, lrow % 32 == 0;
+ * splits > 1: workspace of splits * taps * Cin * Cout floats, reduced in a fixed order.  max_order 2: six products, 0: one (bf16). */
+int ndet_wgrad_split(const float* x_ndhwc, int D, int H, int W, int Cin, const int* kernel, const int* stride, const int* pad,
+                     const uint16_t* dy_planes, int Cout, int lrow, int splits, int max_order, void* workspace, float* dw_rows,
+                     void* stream);
+
 /* ---- backward passes (training).  The reference obtains these from autograd over its materialised tensors; each
  * entry point names the forward statement it differentiates.  Scatter targets must be zero-initialised by the caller;
  * accumulation uses float atomics (order not fixed). ---- */

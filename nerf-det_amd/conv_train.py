@@ -79,6 +79,10 @@ def eligible(conv: nn.Module, x: Tensor) -> bool:
             and conv.in_channels % 32 == 0)
 
 
+IMPLICIT_WGRAD = True     # multi-tap weight gradients on large grids read x in place (k_wgrad_split); False: always the staged form
+                          # (tap copies by k_wgrad_rows + one GEMM)
+
+
 def _rows(x: Tensor, k3, stride3, pads, t0: int, n_taps: int, lrow: int) -> Tensor:
     """csrc/pipeline_kernels.hip::k_wgrad_rows: (D,H,W,C) -> (n_taps, C, lrow) channel-major rows over the convolution's output grid."""
     import ctypes
@@ -92,7 +96,7 @@ def _rows(x: Tensor, k3, stride3, pads, t0: int, n_taps: int, lrow: int) -> Tens
     return out
 
 
-def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pads=None) -> Tensor:
+def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pads=None, implicit=None) -> Tensor:
     """dW of a convolution of uniform stride (same-padded unless ``pads`` says otherwise).  x (D,H,W,Cin), g (OD,OH,OW,Cout) contiguous fp32
     channels-last (2D: D = batch, kernel (kh,kw)) -> (Cout, Cin, *kernel) in torch's layout."""
     two_d = len(kernel) == 2
@@ -109,6 +113,29 @@ def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pa
     grows = _rows(g, (1, 1, 1), (1, 1, 1), (0, 0, 0), 0, 1, lrow)
     pk = dict(w=grows, scale=None, shift=None, cout=cout, cin=lrow, ksize=1, stride=1, transposed=False, kernel=(1, 1), strides=(1, 1),
               pads=(0, 0), ndim=2)
+    if implicit is None:
+        implicit = IMPLICIT_WGRAD and taps >= 9 and lo >= 16384
+    if implicit and C.ARITHMETIC in ("bf16x3", "bf16") and cin % 64 == 0:
+        # multi-tap layers on large grids: x read in place (csrc/conv_split_kernels.hip::k_wgrad_split), no tap copies -- there the staged
+        # form writes and re-reads taps x the input (707 MB for a 3x3x3 layer at 40x40x16x256); on small grids and 1x1 layers the staged
+        # GEMM runs on the faster tiles and wins (tools/bench_wgrad.py)
+        import ctypes
+        from ctypes import c_void_p
+        from . import _lib
+        planes = C.split_planes(pk)
+        bm, bn = (128 if cin % 128 == 0 else 64), (128 if cout > 64 else 64)
+        tiles = (taps * cin // bm) * ((cout + bn - 1) // bn)
+        ksteps = lrow // 32
+        splits = max(1, min(32, ksteps // 8, -(-768 // tiles)))
+        m = taps * cin
+        ws = torch.empty((splits * m * cout,), dtype=torch.float32, device=x.device) if splits > 1 else None
+        dw = torch.empty((m, cout), dtype=torch.float32, device=x.device)
+        i3 = lambda v: (ctypes.c_int * 3)(*v)
+        st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(_lib.load().ndet_wgrad_split(c_void_p(x.data_ptr()), d, h, w, cin, i3(k3), i3(s3), i3(pads), c_void_p(planes.data_ptr()), cout, lrow,
+                                                splits, 0 if C.ARITHMETIC == "bf16" else 2, c_void_p(0 if ws is None else ws.data_ptr()),
+                                                c_void_p(dw.data_ptr()), st), "wgrad_split")
+        return dw.view(taps, cin, cout).permute(2, 1, 0).reshape(cout, cin, *kernel)
     per = max(1, min(taps, (1 << 30) // (cin * lrow * 4)))  # the kernel addresses its operand with 32-bit byte offsets: <= 1 GiB per launch
     parts = []
     for t0 in range(0, taps, per):

@@ -461,6 +461,197 @@ __global__ __launch_bounds__(256, MID == 64 ? 3 : 2) void k_conv_split_chain(con
 
 
 // ------------------------------------------------------------------------------------------------
+// Weight gradient as an implicit GEMM, the tap copies of x never materialised:
+//     dW[(t, ci)][co] = sum_j x[s o(j) + t - p][ci] . dy[j][co]             (j = output voxel; autograd of nn.Conv3d / nn.Conv2d,
+// mmdet3d/models/necks/imvoxelnet.py:22-67,233-260).  GEMM rows = (tap, input channel), columns = output channels, contraction over the
+// output voxels.  The B operand is dy staged channel-major and split once (k_wgrad_rows + k_split_weights, 1x its size); the A operand is
+// read straight from channels-last x: a K step is 32 output voxels x BM channels of ONE tap -- 32 coalesced BM x 4-byte runs -- and
+// is transposed on its way into LDS (a thread holds four channels of one voxel and writes four 2-byte elements per plane).  With
+// k_wgrad_rows staging x as well, a 3x3x3 layer wrote and re-read 27 copies of its input (707 MB at 40x40x16x256).
+// Split-K over the voxels with the fixed-order reduction of the convolutions.
+// ------------------------------------------------------------------------------------------------
+struct WgradParams {
+    const float* x;        // (D, H, W, Cin) channels-last
+    int D, H, W, Cin;
+    int kh, kw;            // taps per axis below the depth axis (tap t -> (t / (kh kw), (t / kw) % kh, t % kw))
+    int pd, ph, pw, sd, sh, sw;
+    int OD, OH, OW;
+    int L;                 // output voxels = OD OH OW
+    int ksteps;            // K steps of 32 voxels (dy rows are zero-filled past L)
+};
+
+template <int BM, int BN, bool ONE>
+__global__ __launch_bounds__(256, 2) void k_wgrad_split(const WgradParams g, const Conv3dParams p, const uint16_t* __restrict__ gsplit) {
+    constexpr int NTHR = 256, WGM = 2, WGN = 2;
+    constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
+    constexpr int CQ = BM / 4;              // channel quads of the A tile
+    constexpr int VG = NTHR / CQ;           // voxel groups staged side by side (8 at BM = 128, 16 at BM = 64)
+    constexpr int VT = 32 / VG;             // consecutive voxels per thread (4 / 2): a thread transposes a VT x 4 block in registers
+    constexpr int RPB = NTHR / 4, BR = BN / RPB;
+    static_assert((VT == 4 || VT == 2) && BR >= 1 && MT >= 1 && NT >= 1, "tile too small for the thread count");
+    constexpr int NPL = ONE ? 1 : 3;
+    constexpr int APL = BM * SPL_RS, BPL = BN * SPL_RS;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
+    uint16_t* As = lds16;
+    uint16_t* Bs = lds16 + NPL * APL;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int tap = m0 / g.Cin, ci0 = m0 - tap * g.Cin;    // Cin % BM == 0: a tile never straddles two taps
+    const int ta = tap / (g.kh * g.kw), tb = (tap / g.kw) % g.kh, tc = tap % g.kw;
+    const int cq = tid % CQ, vg = tid / CQ;
+    const int bkg = tid & 3, brow_ = tid >> 2;
+
+    int it_begin = 0, it_end = g.ksteps;
+    if (p.splits > 1) {
+        it_begin = (int)((int64_t)g.ksteps * blockIdx.z / p.splits);
+        it_end = (int)((int64_t)g.ksteps * (blockIdx.z + 1) / p.splits);
+    }
+    // output voxel of each of this thread's VT slots (consecutive voxels vg*VT .. +VT-1 of the step), advanced by 32 per step
+    int od[VT], oh[VT], ow[VT];
+#pragma unroll
+    for (int i = 0; i < VT; ++i) {
+        const int j = it_begin * 32 + vg * VT + i;
+        ow[i] = j % g.OW; oh[i] = (j / g.OW) % g.OH; od[i] = j / (g.OW * g.OH);
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 ra[VT];
+    uint4 rb[BR][NPL];
+    const int64_t wtile = (int64_t)p.Cout * CBK;
+    bool bok[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) bok[i] = n0 + brow_ + RPB * i < p.Cout;
+    const uint16_t* bbase_g = gsplit + (int64_t)(n0 + brow_) * CBK + bkg * 8;
+    const float* xbase = g.x + ci0 + cq * 4;
+    int nit = it_begin;
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < VT; ++i) {
+            const int d_ = od[i] * g.sd + ta - g.pd, h_ = oh[i] * g.sh + tb - g.ph, w_ = ow[i] * g.sw + tc - g.pw;
+            const bool ok = od[i] < g.OD && (unsigned)d_ < (unsigned)g.D && (unsigned)h_ < (unsigned)g.H && (unsigned)w_ < (unsigned)g.W;
+            const float4 v = *reinterpret_cast<const float4*>(ok ? xbase + (((int64_t)d_ * g.H + h_) * g.W + w_) * g.Cin : xbase);   // always issued
+            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            ow[i] += 32;                                   // the slot's voxel of the next step
+            while (ow[i] >= g.OW) {
+                ow[i] -= g.OW;
+                if (++oh[i] == g.OH) { oh[i] = 0; ++od[i]; }
+            }
+        }
+        const uint16_t* bt = bbase_g + (int64_t)nit * 3 * wtile;
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                const uint4 v = *reinterpret_cast<const uint4*>(bok[i] ? bt + pl * wtile + (int64_t)RPB * i * CBK : gsplit + bkg * 8);
+                rb[i][pl] = bok[i] ? v : make_uint4(0u, 0u, 0u, 0u);
+            }
+        ++nit;
+    };
+    // A tile in LDS: row = channel, 32 voxels of the step along the row (SPL_RS pitch).  The 8-voxel group index is XORed with
+    // (row >> 4) & 3: the lanes of one store (rows 4 apart, 16 banks apart) then land in different 4-dword groups.
+    auto store_tile = [&]() {
+        const float* rf = reinterpret_cast<const float*>(ra);      // rf[4 * i + e]: voxel slot i, channel e of the quad
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = cq * 4 + e;
+            const int k0 = vg * VT;                                 // first voxel slot of this thread
+            uint16_t* dst = As + row * SPL_RS + ((((k0 >> 3) ^ ((row >> 4) & 3)) << 3) | (k0 & 7));
+            if (VT == 4) {
+                uint2 s0, s1, s2;
+                const float4 v = make_float4(rf[e], rf[4 + e], rf[8 + e], rf[12 + e]);
+                if (ONE) s0 = make_uint2(spl_pack(v.x, v.y), spl_pack(v.z, v.w));
+                else spl_split4(v, s0, s1, s2);
+                *reinterpret_cast<uint2*>(dst) = s0;
+                if (!ONE) {
+                    *reinterpret_cast<uint2*>(dst + APL) = s1;
+                    *reinterpret_cast<uint2*>(dst + 2 * APL) = s2;
+                }
+            } else {
+                const float a_ = rf[e], b_ = rf[4 + e];
+                const uint32_t o0 = spl_pack(a_, b_);
+                *reinterpret_cast<uint32_t*>(dst) = o0;
+                if (!ONE) {
+                    const float r0 = a_ - spl_lo(o0), r1 = b_ - spl_hi(o0);
+                    const uint32_t o1 = spl_pack(r0, r1);
+                    *reinterpret_cast<uint32_t*>(dst + APL) = o1;
+                    *reinterpret_cast<uint32_t*>(dst + 2 * APL) = spl_pack(r0 - spl_lo(o1), r1 - spl_hi(o1));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            uint16_t* dst = Bs + (brow_ + RPB * i) * SPL_RS + bkg * 8;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint4*>(dst + pl * BPL) = rb[i][pl];
+        }
+    };
+    if (it_begin < it_end) {
+        load_tile();
+        store_tile();
+    }
+    __syncthreads();
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    const uint16_t* abase = As + (wm * WM + frow) * SPL_RS;
+    const uint16_t* bbase = Bs + (wn * WN + frow) * SPL_RS + fk;
+    for (int it = it_begin; it < it_end; ++it) {
+        const bool more = it + 1 < it_end;
+        if (more) load_tile();
+#pragma unroll
+        for (int ks = 0; ks < CBK / 16; ++ks) {
+            bf16x8 fa[NPL][MT], fb[NPL][NT];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    fa[pl][t] = *reinterpret_cast<const bf16x8*>(abase + pl * APL + t * 32 * SPL_RS + (((2 * ks + (lane >> 5)) ^ (((wm * WM + t * 32 + frow) >> 4) & 3)) << 3));
+#pragma unroll
+                for (int t = 0; t < NT; ++t) fb[pl][t] = *reinterpret_cast<const bf16x8*>(bbase + pl * BPL + t * 32 * SPL_RS + ks * 16);
+            }
+#pragma unroll
+            for (int order = NPL - 1; order >= 0; --order)
+                if (order <= p.max_order)
+#pragma unroll
+                for (int pa = 0; pa <= order; ++pa) {
+                    const int pb = order - pa;
+#pragma unroll
+                    for (int ta_ = 0; ta_ < MT; ++ta_)
+#pragma unroll
+                        for (int tb_ = 0; tb_ < NT; ++tb_)
+                            acc[ta_][tb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][ta_], fb[pb][tb_], acc[ta_][tb_], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (more) store_tile();
+        __syncthreads();
+    }
+    constexpr int CLDC = BN + 4;
+    float* Cs = reinterpret_cast<float*>(lds16);
+    for (int h = 0; h < WGM; ++h) {
+        if (wm == h) {
+#pragma unroll
+            for (int ta_ = 0; ta_ < MT; ++ta_)
+#pragma unroll
+                for (int tb_ = 0; tb_ < NT; ++tb_)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        Cs[(ta_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CLDC + wn * WN + tb_ * 32 + (lane & 31)] = acc[ta_][tb_][r];
+        }
+        __syncthreads();
+        conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, 0, blockIdx.z);
+        __syncthreads();
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // Wave-specialised 128 x 256 tile (the 256-channel layers of the neck and the FPN): 4 consumer waves (2 x 2, wave tile
 // 64 x 128: 96 MFMAs per K step, nothing else) + 4 producer waves (one per SIMD: loads, the A split, LDS fills of the
 // other of two stages).  Measured on the 128 x 128 tile: staging costs a wave ~2400 cycles per K step on its own (one
@@ -1348,5 +1539,59 @@ extern "C" int ndet_conv_chain_split(const float* in, const uint16_t* w_planes, 
     if (rc != NDET_OK) return rc;
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
+}
+
+template <int BM, int BN, bool ONE>
+static int wgrad_launch(const WgradParams& g, const Conv3dParams& p, const uint16_t* gplanes, hipStream_t st) {
+    dim3 grid(p.M / BM, (p.Cout + BN - 1) / BN, p.splits);
+    size_t lds = (size_t)(ONE ? 1 : 3) * (BM + BN) * SPL_RS * sizeof(uint16_t);
+    const size_t cs = (size_t)(BM / 2) * (BN + 4) * sizeof(float);
+    if (cs > lds) lds = cs;
+    hipLaunchKernelGGL((k_wgrad_split<BM, BN, ONE>), grid, dim3(256), lds, st, g, p, gplanes);
+    return NDET_OK;
+}
+
+extern "C" int ndet_wgrad_split(const float* x_ndhwc, int D, int H, int W, int Cin, const int* kernel, const int* stride, const int* pad,
+                                const uint16_t* dy_planes, int Cout, int lrow, int splits, int max_order, void* workspace, float* dw_rows,
+                                void* stream) {
+    const char* fn = "ndet_wgrad_split";
+    NDET_REQUIRE(x_ndhwc && kernel && stride && pad && dy_planes && dw_rows, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && lrow > 0 && lrow % CBK == 0, NDET_E_INVALID, "%s: bad sizes", fn);
+    NDET_REQUIRE(Cin % 64 == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of 64", fn, Cin);
+    NDET_REQUIRE(max_order == 0 || max_order == 2, NDET_E_INVALID, "%s: bad arithmetic", fn);
+    NDET_REQUIRE((((uintptr_t)x_ndhwc | (uintptr_t)dy_planes | (uintptr_t)dw_rows) & 15) == 0, NDET_E_UNSUPPORTED, "%s: pointers must be 16-byte aligned", fn);
+    WgradParams g;
+    g.x = x_ndhwc; g.D = D; g.H = H; g.W = W; g.Cin = Cin;
+    for (int a = 0; a < 3; ++a)
+        NDET_REQUIRE(kernel[a] >= 1 && kernel[a] <= 7 && stride[a] >= 1 && stride[a] <= 4 && pad[a] >= 0 && pad[a] < kernel[a], NDET_E_UNSUPPORTED,
+                     "%s: kernel/stride/pad out of range on axis %d", fn, a);
+    g.kh = kernel[1]; g.kw = kernel[2];
+    g.pd = pad[0]; g.ph = pad[1]; g.pw = pad[2]; g.sd = stride[0]; g.sh = stride[1]; g.sw = stride[2];
+    g.OD = (D + 2 * pad[0] - kernel[0]) / stride[0] + 1;
+    g.OH = (H + 2 * pad[1] - kernel[1]) / stride[1] + 1;
+    g.OW = (W + 2 * pad[2] - kernel[2]) / stride[2] + 1;
+    NDET_REQUIRE(g.OD > 0 && g.OH > 0 && g.OW > 0 && (int64_t)g.OD * g.OH * g.OW <= lrow && (int64_t)D * H * W * Cin < ((int64_t)1 << 40),
+                 NDET_E_INVALID, "%s: dy rows (%d) shorter than the output grid", fn, lrow);
+    g.L = g.OD * g.OH * g.OW;
+    g.ksteps = lrow / CBK;
+    const int taps = kernel[0] * kernel[1] * kernel[2];
+    Conv3dParams p;
+    p.in = nullptr; p.w = nullptr; p.out = dw_rows; p.scale = nullptr; p.shift = nullptr; p.res = nullptr; p.partial = (float*)workspace;
+    p.D = p.H = p.W = 1; p.Cin = lrow; p.Cout = Cout; p.OD = p.OH = 1; p.OW = taps * Cin;
+    p.kd = p.kh = p.kw = 1; p.sd = p.sh = p.sw = 1; p.pd = p.ph = p.pw = 0;
+    p.relu = 0; p.transposed = 0; p.M = taps * Cin; p.res_up2 = 0; p.RH = p.RW = 0; p.max_order = max_order; p.xscale = 1.0f;
+    p.splits = splits < 1 ? 1 : splits;
+    NDET_REQUIRE(p.splits <= g.ksteps, NDET_E_INVALID, "%s: splits=%d exceeds the %d K steps", fn, p.splits, g.ksteps);
+    NDET_REQUIRE(p.splits == 1 || workspace != nullptr, NDET_E_INVALID, "%s: split-K needs a workspace", fn);
+    hipStream_t st = (hipStream_t)stream;
+    const bool one = max_order == 0, wide = Cout > 64, big = Cin % 128 == 0;
+    int rc;
+    if (big && wide) rc = one ? wgrad_launch<128, 128, true>(g, p, dy_planes, st) : wgrad_launch<128, 128, false>(g, p, dy_planes, st);
+    else if (big) rc = one ? wgrad_launch<128, 64, true>(g, p, dy_planes, st) : wgrad_launch<128, 64, false>(g, p, dy_planes, st);
+    else if (wide) rc = one ? wgrad_launch<64, 128, true>(g, p, dy_planes, st) : wgrad_launch<64, 128, false>(g, p, dy_planes, st);
+    else rc = one ? wgrad_launch<64, 64, true>(g, p, dy_planes, st) : wgrad_launch<64, 64, false>(g, p, dy_planes, st);
+    if (rc != NDET_OK) return rc;
+    NDET_CHECK_LAUNCH(fn);
+    return conv_splitk_reduce_launch(p, st, fn);
 }
 

@@ -158,3 +158,30 @@ def test_bottleneck_training_forward_backward_vs_fp64(device):
     assert _rel(ours[0], exact[0]) <= 2e-5 and _rel(ours[1], exact[1]) <= 2e-5
     for n in exact[2]:
         assert _rel(ours[2][n], exact[2][n]) <= 5e-5, n
+
+
+@pytest.mark.parametrize("dims,cin,cout,kernel,stride,pads", [((12, 10, 6), 128, 64, (3, 3, 3), 1, None), ((9, 8, 6), 64, 128, (3, 3, 3), 2, None),
+                                                              ((8, 8, 4), 128, 25, (3, 3, 3), 1, None), ((10, 6, 4), 256, 96, (2, 2, 2), 2, (0, 0, 0)),
+                                                              ((3, 11, 14), 64, 64, (3, 3), 2, None), ((2, 9, 12), 192, 256, (1, 1), 1, None)])
+def test_implicit_weight_gradient_equals_the_staged_form(device, dims, cin, cout, kernel, stride, pads):
+    """k_wgrad_split (x read in place, transposed into LDS) against the staged form (tap copies + one GEMM): the same products summed in
+    another order, and both against an fp64 evaluation of the sum."""
+    from nerfdet_amd import conv_train
+    torch.manual_seed(cin + cout)
+    two_d = len(kernel) == 2
+    k3 = ((1,) + tuple(kernel)) if two_d else tuple(kernel)
+    s3 = (1, stride, stride) if two_d else (stride,) * 3
+    p3 = tuple(v // 2 for v in k3) if pads is None else tuple(pads)
+    out_dims = tuple((n + 2 * p - k) // s + 1 for n, p, k, s in zip(dims, p3, k3, s3))
+    x = torch.randn(*dims, cin, device=device)
+    g = torch.randn(*out_dims, cout, device=device)
+    staged = conv_train.weight_grad(x, g, kernel, stride, pads, implicit=False)
+    implicit = conv_train.weight_grad(x, g, kernel, stride, pads, implicit=True)
+    xd, gd = x.double().cpu(), g.double().cpu()
+    if two_d:
+        xd, gd = xd.unsqueeze(0).permute(0, 4, 1, 2, 3), gd.unsqueeze(0).permute(0, 4, 1, 2, 3)      # (1, C, N, H, W): the batch as a depth axis
+    else:
+        xd, gd = xd.permute(3, 0, 1, 2).unsqueeze(0), gd.permute(3, 0, 1, 2).unsqueeze(0)
+    exact = torch.nn.grad.conv3d_weight(xd, (cout, cin) + k3, gd, stride=s3, padding=p3).reshape(staged.shape)
+    assert implicit.shape == staged.shape
+    assert _rel(implicit.cpu().double(), exact) <= 2e-5 and _rel(staged.cpu().double(), exact) <= 2e-5

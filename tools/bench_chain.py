@@ -42,7 +42,7 @@ def main():
         m = views * oh * ow
         gf = 2 * m * mid * (cin * 9 + cout) / 1e9
         mb = 4 * (x.numel() + res.numel() * 2) / 1e6
-        print(f"{name:26s} conv2 {t2:7.1f} us + conv3 {t3:7.1f} us = {t2 + t3:7.1f} | chained {tc:7.1f} us  {gf / tc * 1e-3:6.1f} TF  {mb / tc * 1e-6:5.2f} TB/s  maxdiff {d:.2e}", flush=True)
+        print(f"{name:26s} conv2 {t2:7.1f} us + conv3 {t3:7.1f} us = {t2 + t3:7.1f} | chained {tc:7.1f} us  {gf / tc * 1e3:6.1f} TF  {mb / tc:5.2f} TB/s  maxdiff {d:.2e}", flush=True)
 
 
 main()
