@@ -193,7 +193,12 @@ class nerfdet(BaseDetector):
         return self.simple_test(img, img_metas, ray_batch=rb or None)
 
     def simple_test(self, img, img_metas, depth=None, ray_batch=None, evaluate_nerf=False):
-        x, valids, _, _, _ = self.extract_feat(img, img_metas, "test", depth, ray_batch)
+        x, valids, _, rgb_preds, _ = self.extract_feat(img, img_metas, "test", depth, ray_batch)
+        if evaluate_nerf:
+            # nerfdet.py:342-343 computes (psnr, ssim, rmse) with save_rendered_img and drops them; kept here for the caller, without the PNGs
+            from .rays import rendering_metrics
+            assert rgb_preds and rgb_preds[-1] is not None, "evaluate_nerf needs render_testing=True (render_ray.py:452-517)"
+            self.render_metrics = rendering_metrics(rgb_preds[-1])
         for m in img_metas:
             m.setdefault("box_type_3d", DepthInstance3DBoxes)
         if hasattr(self.bbox_head, "can_fuse") and self.bbox_head.can_fuse(x) and len(img_metas) == 1:

@@ -319,7 +319,37 @@ def render_rays(ray_batch, mean_volume, cov_volume, features_2D, img, aabb, near
 
 def compute_psnr(pred: Tensor, target: Tensor, mask: Optional[Tensor] = None) -> Tensor:
     """PSNR of a rendered view against its ground truth, maximum pixel value 1: ``-10 log10(mean((pred - target)^2))``
-    (model_utils/save_rendered_img.py:10-19; the image dump and SSIM of that module are visualisation, out of scope)."""
+    (model_utils/save_rendered_img.py:10-19)."""
     if mask is not None:
         pred, target = pred[mask], target[mask]
     return -10.0 * torch.log(((pred - target) ** 2).mean()) / float(np.log(10.0))
+
+
+def compute_ssim(pred: Tensor, target: Tensor) -> Tensor:
+    """SSIM of a rendered (H,W,3) view as the reference's ``compute_ssim`` obtains it (model_utils/save_rendered_img.py:21-36 ->
+    ``skimage.metrics.structural_similarity(..., multichannel=True)`` of the pinned scikit-image 0.18.1): per channel, 7 x 7 uniform
+    window, sample covariance, K1 = 0.01, K2 = 0.03, data range 2 (float images), float64, mean over the window-valid interior, then over
+    the channels.  The 49-pixel box means are one average pooling each, on the device."""
+    assert pred.shape == target.shape and pred.dim() == 3 and pred.shape[-1] == 3 and min(pred.shape[:2]) >= 7
+    x, y = pred.permute(2, 0, 1).unsqueeze(0).double(), target.permute(2, 0, 1).unsqueeze(0).double()
+    box = lambda t: torch.nn.functional.avg_pool2d(t, 7, stride=1)
+    ux, uy, uxx, uyy, uxy = box(x), box(y), box(x * x), box(y * y), box(x * y)
+    norm = 49.0 / 48.0
+    vx, vy, vxy = norm * (uxx - ux * ux), norm * (uyy - uy * uy), norm * (uxy - ux * uy)
+    c1, c2 = (0.01 * 2.0) ** 2, (0.03 * 2.0) ** 2
+    s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
+    return s.mean(dim=(2, 3)).mean()
+
+
+def rendering_metrics(rendered: dict):
+    """What ``save_rendered_img`` returns (model_utils/save_rendered_img.py:38-78) for one ``render_rays(render_testing=True)`` result,
+    without its PNG dump: mean PSNR and mean SSIM over the target views (device scalars) and the mean squared depth error MAP
+    (H,W,1) the reference calls rmse (None without depth maps)."""
+    rgb, gt = rendered["outputs_coarse"]["rgb"], rendered["gt_rgb"]
+    depth, gt_depth = rendered["outputs_coarse"]["depth"], rendered["gt_depth"]
+    n = gt.shape[0]
+    psnr = torch.stack([compute_psnr(rgb[v], gt[v]) for v in range(n)]).mean()
+    ssim = torch.stack([compute_ssim(rgb[v], gt[v]) for v in range(n)]).mean()
+    err = None if gt_depth is None else ((depth - gt_depth) ** 2).mean(dim=0)
+    return psnr, ssim, err
+

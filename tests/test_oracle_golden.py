@@ -170,3 +170,17 @@ def test_nms_random_golden():
         assert 50 < len(pick) < 400
     pick = O.aligned_3d_nms(g["deg_boxes"], g["scores"][:40], torch.zeros(40, dtype=torch.long), 0.25)
     assert torch.equal(pick, g["deg_pick"])
+
+
+def test_render_eval_oracle_ssim_is_the_windowed_definition():
+    """oracle/render_eval_oracle.py: the filter form of SSIM equals the window-by-window definition with sample statistics (scikit-image
+    is absent: parity unpinned, see the module header), identical images score 1, and PSNR follows save_rendered_img.py:10-19."""
+    from oracle import render_eval_oracle as R
+    rng = np.random.RandomState(0)
+    x = rng.rand(12, 15).astype(np.float32)
+    y = np.clip(x + 0.1 * rng.randn(12, 15), 0, 1).astype(np.float32)
+    assert abs(R.ssim_channel(x, y) - R.ssim_by_definition(x, y)) < 1e-12
+    assert abs(R.ssim_channel(x, x) - 1.0) < 1e-12 and R.ssim_channel(x, y) < 0.99
+    img = rng.rand(9, 11, 3).astype(np.float32)
+    assert abs(R.ssim(img, img) - 1.0) < 1e-12
+    assert abs(R.psnr(np.zeros((4, 4, 3), np.float32), np.full((4, 4, 3), 0.1, np.float32)) - 20.0) < 1e-4

@@ -285,3 +285,23 @@ def test_packed_sampler_equals_generic_kernel(device, n_v, d, hw):
     scale = float(outs[1].abs().max())
     assert scale > 0
     assert float((outs[0] - outs[1]).abs().max()) <= 1e-4 * scale
+
+
+def test_rendering_metrics_match_the_cpu_restatement(device):
+    """f-4: PSNR / SSIM / depth-error map of ``simple_test(evaluate_nerf=True)`` (nerfdet.py:342-343, save_rendered_img.py:38-78) on the
+    device against oracle/render_eval_oracle.py (scikit-image's SSIM restated: unpinned, see its header)."""
+    import numpy as np
+    from nerfdet_amd import rays
+    from oracle import render_eval_oracle as R
+    torch.manual_seed(0)
+    gt = torch.rand(3, 20, 27, 3)
+    rgb = (gt + 0.05 * torch.randn_like(gt)).clamp(0, 1)
+    gt_depth = torch.rand(3, 20, 27, 1) * 4
+    depth = gt_depth + 0.1 * torch.randn_like(gt_depth)
+    ret = dict(outputs_coarse=dict(rgb=rgb.to(device), depth=depth.to(device)), gt_rgb=gt.to(device), gt_depth=gt_depth.to(device))
+    psnr, ssim, err = rays.rendering_metrics(ret)
+    p, s, e = R.rendering_metrics(rgb.numpy(), gt.numpy(), depth.numpy(), gt_depth.numpy())
+    assert abs(float(psnr) - p) <= 1e-4 and abs(float(ssim) - s) <= 1e-9
+    assert np.allclose(err.cpu().numpy(), e, rtol=1e-5, atol=1e-7) and err.shape == (20, 27, 1)
+    assert rays.rendering_metrics(dict(ret, gt_depth=None))[2] is None
+    assert abs(float(rays.compute_ssim(gt[0].to(device), gt[0].to(device))) - 1.0) < 1e-12
