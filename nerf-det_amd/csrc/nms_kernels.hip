@@ -498,43 +498,59 @@ __global__ __launch_bounds__(1024) void k_select_candidates_topk(const SelectLev
             K = prefix;
             ties_need = need;
         }
-        // ---- ordered compaction ----
+        // ---- ordered compaction: every thread owns a contiguous run of voxels; two block-wide scans (ties, then kept) give its offsets ----
         const int level_base = base_s;
-        if (tid == 0) { eq_s = 0; raw_s += c; }
-        __syncthreads();
-        for (int i0 = 0; i0 < n_l; i0 += 1024) {
-            const int i = i0 + tid;
-            const float v = i < n_l ? best[i] : 0.0f;
+        const int per = (n_l + 1023) / 1024;
+        const int i_lo = min(tid * per, n_l), i_hi = min(i_lo + per, n_l);
+        int n_gt = 0, n_eq = 0;
+        for (int i = i_lo; i < i_hi; ++i) {
+            const float v = best[i];
+            if (v > thr) {
+                const unsigned key = __float_as_uint(v);
+                n_gt += key > K ? 1 : 0;
+                n_eq += (K != 0u && key == K) ? 1 : 0;
+            }
+        }
+        auto block_exclusive = [&](int x, int* scratch, int& total) {   // exclusive prefix of x over the 1024 threads, in thread order
+            int inc = x;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(inc, off);
+                if (lane >= off) inc += t;
+            }
+            if (lane == 63) scratch[wave] = inc;
+            __syncthreads();
+            int before = 0, all = 0;
+            for (int w2 = 0; w2 < 16; ++w2) {
+                const int t = scratch[w2];
+                before += w2 < wave ? t : 0;
+                all += t;
+            }
+            __syncthreads();
+            total = all;
+            return before + inc - x;
+        };
+        int tot_eq, tot_keep;
+        const int eq_before = block_exclusive(n_eq, wave_eq, tot_eq);
+        const int eq_keep = max(0, min(n_eq, ties_need - eq_before));      // ties kept in this run: the first ones in voxel order
+        const int off0 = block_exclusive(n_gt + eq_keep, wave_cnt, tot_keep);
+        int o = level_base + off0, eq_left = eq_keep;
+        for (int i = i_lo; i < i_hi; ++i) {
+            const float v = best[i];
+            if (!(v > thr)) continue;
             const unsigned key = __float_as_uint(v);
-            const bool surv = i < n_l && v > thr;
-            const bool eq = surv && K != 0u && key == K;
-            const unsigned long long m_eq = __ballot(eq);
-            if (lane == 0) wave_eq[wave] = __popcll(m_eq);
-            __syncthreads();
-            int eq_before = eq_s + __popcll(m_eq & ((1ull << lane) - 1ull));
-            for (int w2 = 0; w2 < wave; ++w2) eq_before += wave_eq[w2];
-            const bool keep = surv && (key > K || (eq && eq_before < ties_need));
-            const unsigned long long m = __ballot(keep);
-            if (lane == 0) wave_cnt[wave] = __popcll(m);
-            __syncthreads();
-            int off = base_s;
-            for (int w2 = 0; w2 < wave; ++w2) off += wave_cnt[w2];
+            bool keep = key > K;
+            if (!keep && K != 0u && key == K && eq_left > 0) { keep = true; --eq_left; }
             if (keep) {
-                const int o = off + __popcll(m & ((1ull << lane) - 1ull));
                 o_best[o] = v;
                 o_label[o] = lv.label[l][i];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) o_boxes[(int64_t)o * 6 + k] = lv.boxes[l][(int64_t)i * 6 + k];
+                ++o;
             }
-            __syncthreads();
-            if (tid == 0) {
-                int t = 0, e = 0;
-                for (int w2 = 0; w2 < 16; ++w2) { t += wave_cnt[w2]; e += wave_eq[w2]; }
-                base_s += t;
-                eq_s += e;
-            }
-            __syncthreads();
         }
+        if (tid == 0) { base_s = level_base + tot_keep; raw_s += c; }
+        __syncthreads();
         if (tid == 0) counts[l] = base_s - level_base;
     }
     if (tid == 0) { counts[lv.n_levels] = base_s; counts[lv.n_levels + 1] = raw_s; }
