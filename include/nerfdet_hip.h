@@ -300,6 +300,18 @@ int ndet_conv_ndhwc_f16x2(const float* in, const uint16_t* w_planes_f16, float* 
 int ndet_bn_relu_maxpool_nhwc(const float* x, const float* scale, const float* shift, int N, int H, int W, int C,
                               float* out, void* stream);
 
+/* ResNet stem in ONE launch: Conv2d(3, 64, 7, stride 2, pad 3, no bias) + BatchNorm(eval, as per-channel scale/shift) + ReLU +
+ * MaxPool(3, stride 2, pad 1) -- conv1 / bn1 / relu / maxpool of the third-party mmdet ResNet called at
+ * mmdet3d/models/detectors/nerfdet.py:140.  images: N views of 3 x H x W fp32 with the given ELEMENT strides (NCHW or channels-last);
+ * w_planes: ndet_stem_pack_weights of the (64,3,7,7) weight; out (N, PH, PW, 64) channels-last, PH = ((H-1)/2+1 - 1)/2 + 1.
+ * Arithmetic of ndet_conv_ndhwc_split (fp32 operands as exact sums of three bf16 terms, six MFMA products). */
+int ndet_stem_pack_weights(const float* w_64x3x7x7, uint16_t* planes /* (3, 64, 176) */, void* stream);
+
+/* The launch itself (see above; conv1 / bn1 / relu / maxpool behind mmdet3d/models/detectors/nerfdet.py:140). */
+int ndet_stem_conv_bn_relu_maxpool(const float* images, int N, int H, int W, int64_t stride_n, int64_t stride_c, int64_t stride_y,
+                                   int64_t stride_x, const uint16_t* w_planes, const float* scale, const float* shift, float* out,
+                                   void* stream);
+
 /* ---- input contract: what the data pipeline hands to nerfdet.forward_*, from decoded,
  * resized and padded uint8 BGR frames (n_frames,H,W,3) resident on the device.  mean_rgb / std_rgb are HOST arrays of 3
  * doubles (the config's img_norm_cfg); the image arithmetic is float32 with stdinv = float(1 / std), as mmcv does it.

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .conv3d import bn_relu_maxpool_nhwc, chain_ok, conv2d_chain_nhwc, conv2d_nhwc, packed
+from .conv3d import bn_relu_maxpool_nhwc, chain_ok, conv2d_chain_nhwc, conv2d_nhwc, packed, stem_conv_bn_relu_maxpool, stem_ok
 from .conv_train import conv_bn_act, conv_forward
 from .registry import BACKBONES, NECKS
 
@@ -139,7 +139,7 @@ class ResNet(nn.Module):
         library modules."""
         outs = []
         with torch.no_grad():
-            y = bn_relu_maxpool_nhwc(_nhwc(self.conv1(x)), self.bn1)
+            y = self._stem(x)
             for i in range(self.frozen_stages):
                 for blk in getattr(self, f"layer{i + 1}"):
                     y = blk.forward_nhwc(y)
@@ -152,11 +152,17 @@ class ResNet(nn.Module):
                 outs.append(y)
         return tuple(outs)
 
+    def _stem(self, x):
+        """conv1 + bn1 (eval) + ReLU + max-pool -> (N,H/4,W/4,64) channels-last: one launch (csrc/stem_kernels.hip); with the exact
+        fp32-MFMA arithmetic selected, the vendor library's convolution followed by the fused BN + ReLU + pool pass."""
+        if stem_ok(self.conv1, self.bn1, x):
+            return stem_conv_bn_relu_maxpool(x, self.conv1, self.bn1)
+        return bn_relu_maxpool_nhwc(_nhwc(self.conv1(x.contiguous(memory_format=torch.channels_last))), self.bn1)
+
     use_hip = True  # inference on the GPU: bottlenecks through the fused MFMA convolution (csrc/conv3d_kernels.hip)
 
     def forward_hip(self, x):
-        # the 7x7 stem conv (Cin = 3) stays on the vendor library; BN + ReLU + max-pool follow in one pass
-        x = bn_relu_maxpool_nhwc(_nhwc(self.conv1(x)), self.bn1)
+        x = self._stem(x)
         outs = []
         for i in range(self.num_stages):
             for blk in getattr(self, f"layer{i + 1}"):
@@ -166,6 +172,8 @@ class ResNet(nn.Module):
         return tuple(outs)
 
     def forward_library(self, x):
+        if x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)      # the layout the library's convolutions are fastest in
         x = F.relu(self.bn1(self.conv1(x)), inplace=True)
         x = F.max_pool2d(x, 3, 2, 1)
         outs = []

@@ -366,6 +366,36 @@ def bn_relu_maxpool_nhwc(x: torch.Tensor, bn: nn.BatchNorm2d) -> torch.Tensor:
     return out
 
 
+def stem_ok(conv: nn.Module, bn: nn.Module, x: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and isinstance(conv, nn.Conv2d) and conv.in_channels == 3 and conv.out_channels == 64
+            and tuple(conv.kernel_size) == (7, 7) and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (3, 3) and conv.bias is None
+            and not bn.training and ARITHMETIC == "bf16x3" and min(x.shape[2:]) >= 7)
+
+
+def stem_conv_bn_relu_maxpool(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d) -> torch.Tensor:
+    """maxpool(relu(bn_eval(conv7x7s2(x)))) of the ResNet stem in one launch (csrc/stem_kernels.hip): logical (N,3,H,W) images in any
+    strided layout -> (N, PH, PW, 64) channels-last."""
+    assert stem_ok(conv, bn, x)
+    n, _, h, w = x.shape
+    store = conv.__dict__.setdefault("_ndet_packed", {})
+    stamp = (conv.weight.data_ptr(), conv.weight._version)
+    hit = store.get("stem")
+    lib = _lib.load()
+    st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    if hit is None or hit[0] != stamp:
+        planes = torch.empty((3, 64, 176), dtype=torch.int16, device=x.device)
+        check(lib.ndet_stem_pack_weights(_ptr(conv.weight.detach().float().contiguous()), _ptr(planes), st), "stem_pack_weights")
+        hit = store["stem"] = (stamp, planes)
+    scale, shift = bn_affine(bn)
+    ch, cw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.empty((n, (ch - 1) // 2 + 1, (cw - 1) // 2 + 1, 64), dtype=torch.float32, device=x.device)
+    sn, sc, sy, sx = x.stride()
+    trace.span("k_stem_conv_pool", lambda: check(lib.ndet_stem_conv_bn_relu_maxpool(_ptr(x), n, h, w, sn, sc, sy, sx, _ptr(hit[1]), _ptr(scale), _ptr(shift),
+                                                                                  _ptr(out), st), "stem_conv_bn_relu_maxpool"),
+               flops=2 * n * ch * cw * 64 * 147, bytes=4 * (x.numel() + out.numel()), kind="stem")
+    return out
+
+
 def to_ndhwc(x: torch.Tensor) -> torch.Tensor:
     """logical (C,X,Y,Z) -> contiguous (X,Y,Z,C) (free when the memory already is channels-last)."""
     y = x.permute(1, 2, 3, 0)

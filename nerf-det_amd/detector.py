@@ -102,7 +102,7 @@ class nerfdet(BaseDetector):
     def extract_2d(self, img):
         """(B,n_v,3,H,W) -> FPN level 0 (B,n_v,C,H/4,W/4), channels-last memory (nerfdet.py:134-147)."""
         b = img.shape[0]
-        x = img.reshape([-1] + list(img.shape)[2:]).contiguous(memory_format=torch.channels_last)
+        x = img.reshape([-1] + list(img.shape)[2:])       # the stem kernel reads the images in the layout they arrive in
         x = self.neck(self.backbone(x))[0]
         stride = img.shape[-1] / x.shape[-1]
         assert stride == 4

@@ -392,3 +392,32 @@ def test_conv_chain_matches_torch_fp32_and_the_two_launches(device, cin, mid, co
     assert float((got - two).abs().max()) <= 4e-6 * scale
     assert float((got16 - two16).abs().max()) <= 4e-6 * scale          # one-product arithmetic: same bf16-rounded operands either way
     assert float((got16.cpu() - ref).abs().max()) > 1e-4 * scale          # ... and really one product
+
+
+@pytest.mark.parametrize("nhw,layout", [((3, 64, 96), "nchw"), ((2, 61, 83), "nchw"), ((2, 50, 70), "nhwc"), ((1, 240, 320), "nchw"), ((2, 17, 23), "view")])
+def test_fused_stem_matches_torch_fp32(device, nhw, layout):
+    """k_stem_conv_pool (7x7 stride-2 conv + eval BatchNorm + ReLU + 3x3 stride-2 max-pool in one launch) against PyTorch-CPU fp32 of the
+    same four modules: odd sizes (ragged tiles, pool windows hanging over the border), both image layouts and a strided view."""
+    from nerfdet_amd.conv3d import stem_conv_bn_relu_maxpool, stem_ok
+    torch.manual_seed(sum(nhw))
+    n, h, w = nhw
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+    bn = nn.BatchNorm2d(64).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+    x = torch.randn(n, 3, h, w)
+    with torch.no_grad():
+        ref = F.max_pool2d(F.relu(bn(conv(x))), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+    xd = x.to(device)
+    if layout == "nhwc":
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    elif layout == "view":
+        big = torch.zeros(n, 3, h + 5, w + 9, device=device)
+        big[:, :, 2:2 + h, 4:4 + w] = xd
+        xd = big[:, :, 2:2 + h, 4:4 + w]
+    conv.to(device); bn.to(device)
+    assert stem_ok(conv, bn, xd)
+    with torch.no_grad():
+        got = stem_conv_bn_relu_maxpool(xd, conv, bn)
+    assert got.shape == ref.shape
+    assert float((got.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
