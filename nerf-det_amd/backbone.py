@@ -119,8 +119,22 @@ class ResNet(nn.Module):
                     m.eval()
         return self
 
+    def _bns(self, prefix_only: bool = False):
+        """The BatchNorm modules (of the frozen prefix), listed once: walking ``modules()`` on every call cost 0.2 ms of host time in
+        front of the step's first launch."""
+        key = "_bn_prefix" if prefix_only else "_bn_all"
+        hit = self.__dict__.get(key)
+        if hit is None:
+            if prefix_only:
+                hit = [self.bn1] + [m for i in range(1, self.frozen_stages + 1) for m in getattr(self, f"layer{i}").modules()
+                                    if isinstance(m, nn.BatchNorm2d)]
+            else:
+                hit = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+            self.__dict__[key] = hit
+        return hit
+
     def forward(self, x):
-        bn_frozen = not any(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+        bn_frozen = not any(m.training for m in self._bns())
         if x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and bn_frozen and self.use_hip:
             return self.forward_hip(x)
         if (x.is_cuda and x.dtype == torch.float32 and self.use_hip and self.frozen_stages >= 1 and not x.requires_grad
@@ -129,9 +143,7 @@ class ResNet(nn.Module):
         return self.forward_library(x)
 
     def _frozen_prefix_in_eval(self) -> bool:
-        mods = [self.bn1] + [m for i in range(1, self.frozen_stages + 1) for m in getattr(self, f"layer{i}").modules()
-                             if isinstance(m, nn.BatchNorm2d)]
-        return not any(m.training for m in mods)
+        return not any(m.training for m in self._bns(prefix_only=True))
 
     def forward_frozen_prefix(self, x):
         """Training: the frozen stem and stages (``frozen_stages``, eval-mode BatchNorm, no parameter gradients, no gradient
