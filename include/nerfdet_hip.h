@@ -350,6 +350,13 @@ int ndet_wgrad_split(const float* x_ndhwc, int D, int H, int W, int Cin, const i
                      const uint16_t* dy_planes, int Cout, int lrow, int splits, int max_order, void* workspace, float* dw_rows,
                      void* stream);
 
+/* Backward of the fused epilogue y = relu(conv * scale + shift (+ identity)) -- convolution + frozen eval-mode BatchNorm + ReLU (+ the
+ * bottleneck's identity) of the trainable ResNet stages (mmdet Bottleneck.forward behind mmdet3d/models/detectors/nerfdet.py:140;
+ * config: norm_eval=True, norm_cfg.requires_grad=False): d_identity = dy [y > 0] (null = not wanted), d_conv = d_identity * scale[c],
+ * one pass over `rows` channels-last rows of C floats (C % 4 == 0).  relu = 0: no mask (y may be null). */
+int ndet_relu_affine_bwd(const float* dy, const float* y, const float* scale, int64_t rows, int C, int relu, float* d_identity,
+                         float* d_conv, void* stream);
+
 /* ---- backward passes (training).  The reference obtains these from autograd over its materialised tensors; each
  * entry point names the forward statement it differentiates.  Scatter targets must be zero-initialised by the caller;
  * accumulation uses float atomics (order not fixed). ---- */

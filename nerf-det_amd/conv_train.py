@@ -211,10 +211,14 @@ class ConvAffineAct(torch.autograd.Function):
     def backward(ctx, g):
         x, w, scale, y = ctx.saved_tensors
         g = g.contiguous().float()
-        if ctx.relu:
-            g = g * (y > 0)
-        d_res = g if (ctx.has_res and ctx.needs_input_grad[4]) else None
-        gs = g * scale
+        want_res = ctx.has_res and ctx.needs_input_grad[4]
+        from ctypes import c_void_p
+        from . import _lib
+        d_res = torch.empty_like(g) if want_res else None
+        gs = torch.empty_like(g)
+        _lib.check(_lib.load().ndet_relu_affine_bwd(c_void_p(g.data_ptr()), c_void_p(y.data_ptr() if ctx.relu else 0), c_void_p(scale.data_ptr()),
+                                                    g.numel() // g.shape[-1], g.shape[-1], int(ctx.relu), c_void_p(d_res.data_ptr() if want_res else 0),
+                                                    c_void_p(gs.data_ptr()), c_void_p(torch.cuda.current_stream(g.device).cuda_stream)), "relu_affine_bwd")
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if ctx.stride == 1:

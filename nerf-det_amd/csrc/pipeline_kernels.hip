@@ -166,3 +166,39 @@ extern "C" int ndet_wgrad_rows(const float* x_ndhwc, int D, int H, int W, int C,
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the fused epilogue y = relu(conv * scale + shift (+ identity)) of the frozen-BatchNorm training convolutions
+// (nerfdet_amd/conv_train.py::ConvAffineAct; mmdet's Bottleneck.forward behind mmdet3d/models/detectors/nerfdet.py:140):
+//     gm = dy [y > 0]        the gradient of the identity branch (written when asked for)
+//     gs = gm * scale[c]     what the data / weight gradients of the convolution receive
+// one pass over channels-last rows instead of three library launches (compare, multiply, multiply).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_relu_affine_bwd(const float4* __restrict__ g, const float4* __restrict__ y, const float4* __restrict__ scale,
+                                                        int64_t n4, int c4, int relu, float4* __restrict__ gm, float4* __restrict__ gs) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = g[i];
+    if (relu) {
+        const float4 t = y[i];
+        v.x = t.x > 0.f ? v.x : 0.f; v.y = t.y > 0.f ? v.y : 0.f; v.z = t.z > 0.f ? v.z : 0.f; v.w = t.w > 0.f ? v.w : 0.f;
+    }
+    if (gm) gm[i] = v;
+    const float4 s = scale[i % c4];
+    gs[i] = make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
+}
+
+extern "C" int ndet_relu_affine_bwd(const float* dy, const float* y, const float* scale, int64_t rows, int C, int relu, float* d_identity,
+                                    float* d_conv, void* stream) {
+    const char* fn = "ndet_relu_affine_bwd";
+    NDET_REQUIRE(dy && scale && d_conv && (y || !relu), NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, NDET_E_UNSUPPORTED, "%s: C=%d must be a positive multiple of 4", fn, C);
+    NDET_REQUIRE((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)scale | (uintptr_t)d_identity | (uintptr_t)d_conv) & 15) == 0, NDET_E_UNSUPPORTED,
+                 "%s: pointers must be 16-byte aligned", fn);
+    const int64_t n4 = rows * (C / 4);
+    NDET_REQUIRE((n4 + 255) / 256 < ((int64_t)1 << 31), NDET_E_UNSUPPORTED, "%s: tensor too large", fn);
+    hipLaunchKernelGGL(k_relu_affine_bwd, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)dy, (const float4*)y,
+                       (const float4*)scale, n4, C / 4, relu, (float4*)d_identity, (float4*)d_conv);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
