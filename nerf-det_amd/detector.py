@@ -192,7 +192,7 @@ class nerfdet(BaseDetector):
         rb = self._ray_batch(kwargs)
         return self.simple_test(img, img_metas, ray_batch=rb or None)
 
-    def simple_test(self, img, img_metas, depth=None, ray_batch=None, evaluate_nerf=False):
+    def simple_test(self, img, img_metas, depth=None, ray_batch=None, evaluate_nerf=False, defer=False):
         x, valids, _, rgb_preds, _ = self.extract_feat(img, img_metas, "test", depth, ray_batch)
         if evaluate_nerf:
             # nerfdet.py:342-343 computes (psnr, ssim, rmse) with save_rendered_img and drops them; kept here for the caller, without the PNGs
@@ -202,12 +202,26 @@ class nerfdet(BaseDetector):
         for m in img_metas:
             m.setdefault("box_type_3d", DepthInstance3DBoxes)
         if hasattr(self.bbox_head, "can_fuse") and self.bbox_head.can_fuse(x) and len(img_metas) == 1:
-            bbox_list = self.bbox_head.simple_test_fused(x, valids.float(), img_metas)
+            bbox_list = self.bbox_head.simple_test_fused(x, valids.float(), img_metas, defer=defer)
         else:
             bbox_list = self.bbox_head.get_bboxes(*self.bbox_head(x), valids.float(), img_metas)
+            if defer:
+                ready = bbox_list
+                bbox_list = lambda: ready
+        if defer:
+            pending = bbox_list
+            return lambda: [bbox3d2result(b, s, l) for b, s, l in pending()]
         res = [bbox3d2result(b, s, l) for b, s, l in bbox_list]
         trace.mark("head_nms")
         return res
+
+    def forward_test_async(self, img, img_metas, **kwargs):
+        """Serving form of :meth:`forward_test`: every launch of the scene is queued on the current stream and a ``finish()`` callable is
+        returned; ``finish()`` waits for the scene's single device-to-host copy and returns what ``forward_test`` returns.  Two scenes in
+        flight on two streams keep the queue full across the step boundary and let one scene's small late layers share the chip with the
+        other's backbone (bench.py reports that throughput next to the sequential one)."""
+        rb = self._ray_batch(kwargs)
+        return self.simple_test(img, img_metas, ray_batch=rb or None, defer=True)
 
     def aug_test(self, imgs, img_metas):
         pass

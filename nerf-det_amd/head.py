@@ -156,8 +156,12 @@ class ScanNetImVoxelHeadV2(nn.Module):
         return (x[0].is_cuda and not self.training and not torch.is_grad_enabled() and x[0].shape[1] % 32 == 0
                 and x[0].shape[0] == 1 and self.reg_conv.out_channels == 6)
 
-    def simple_test_fused(self, x, valid, img_metas):
-        """forward + get_bboxes for one scene in a dozen launches: fused head conv -> level mask -> decode (best score, label,
+    def simple_test_fused(self, x, valid, img_metas, defer=False):
+        """``defer=True``: everything is enqueued, the picks travel to a pinned host buffer asynchronously, and a ``finish()`` callable is
+        returned that waits for that copy and builds the detections -- a server keeps a second scene's launches queued (on another
+        stream) while this one drains.  Default: the detections themselves.
+
+        forward + get_bboxes for one scene in a dozen launches: fused head conv -> level mask -> decode (best score, label,
         box per voxel; csrc/nms_kernels.hip::k_head_decode) -> one order-preserving ``score > thr`` compaction over all
         levels -> greedy NMS -> detections.  Same candidates as :meth:`get_bboxes` (imvoxel_head_v2.py:216-285,528-555):
         a level's top-``nms_pre`` cut only matters when more than ``nms_pre`` of its voxels clear the score threshold, and is
@@ -204,16 +208,64 @@ class ScanNetImVoxelHeadV2(nn.Module):
             c_box = torch.empty((tot, 6), dtype=torch.float32, device=dev)
             pa = lambda ts: (ctypes.c_void_p * nl)(*[t.data_ptr() for t in ts])
             counts = torch.empty((nl + 2,), dtype=torch.int32, device=dev)
+            from .boxes import DepthInstance3DBoxes
+
+            def general():
+                # ---- general tail (more than 4096 candidates or 1024 picks, another box container): host-driven ----
+                nonlocal c_best, c_lab, c_box
+                check(lib.ndet_select_candidates(nl, pa(bests), pa(labels), pa(boxes), (ctypes.c_int * nl)(*sizes), float(self.test_cfg.score_thr),
+                                                 c_void_p(c_best.data_ptr()), c_void_p(c_lab.data_ptr()), c_void_p(c_box.data_ptr()),
+                                                 c_void_p(counts.data_ptr()), st), "select_candidates")
+                cnt = counts.cpu().tolist()   # host sync 1 of 2
+                pre = self.test_cfg.nms_pre
+                n = cnt[nl]
+                if pre > 0 and any(c > pre for c in cnt[:nl]):
+                    # a level has more survivors than nms_pre: its top-nms_pre by score (all of them above the threshold, so the
+                    # same set the reference's "top-k, then threshold" keeps); the other levels stay as compacted
+                    pb, plab, pbox, off = [], [], [], 0
+                    for c in cnt[:nl]:
+                        sb, sl, sx = c_best[off:off + c], c_lab[off:off + c], c_box[off:off + c]
+                        if c > pre:
+                            sb, ids = sb.topk(pre)
+                            sl, sx = sl[ids], sx[ids]
+                        pb.append(sb); plab.append(sl); pbox.append(sx)
+                        off += c
+                    c_best, c_lab, c_box = torch.cat(pb), torch.cat(plab), torch.cat(pbox).contiguous()
+                    n = int(c_best.shape[0])
+                if n == 0:
+                    b = meta["box_type_3d"](c_box[:0], origin=(0.5, 0.5, 0.5), box_dim=6, with_yaw=False)
+                    return [(b, c_best[:0], c_lab[:0])]
+                ids = aligned_3d_nms(c_box[:n], c_best[:n], c_lab[:n], self.test_cfg.iou_thr)   # host sync 2
+                k = int(ids.shape[0])
+                o_box = torch.empty((k, 6), dtype=torch.float32, device=dev)
+                o_sc = torch.empty((k,), dtype=torch.float32, device=dev)
+                o_lab = torch.empty((k,), dtype=torch.int64, device=dev)
+                if k:
+                    check(lib.ndet_gather_detections(c_void_p(ids.data_ptr()), k, c_void_p(c_box.data_ptr()), c_void_p(c_best.data_ptr()),
+                                                     c_void_p(c_lab.data_ptr()), c_void_p(o_box.data_ptr()), c_void_p(o_sc.data_ptr()),
+                                                     c_void_p(o_lab.data_ptr()), st), "gather_detections")
+                return [(meta["box_type_3d"](o_box, origin=(0.5, 0.5, 0.5), box_dim=6, with_yaw=False), o_sc, o_lab)]
+
+            def fast(host):
+                """The packed picks on the host -> detections; None when the device-side tail flagged an overflow (status != 0)."""
+                k, status = int(host[0]), int(host[2])
+                if status != 0:
+                    return None
+                rows = host[4:4 + k * 9].view(k, 9)
+                b = object.__new__(DepthInstance3DBoxes)
+                b.tensor, b.box_dim, b.with_yaw = rows[:, :7].contiguous(), 7, False
+                return [(b, rows[:, 7].contiguous(), rows[:, 8].to(torch.int64))]
+
             # ---- fast tail: the per-level top-nms_pre cut, the NMS (candidate count read on the device) and the packing of the picks for
             # ONE device-to-host copy, all enqueued behind the neck's kernels: no host round trip inside the post-processing ----
-            from .boxes import DepthInstance3DBoxes
             if meta["box_type_3d"] is DepthInstance3DBoxes and float(self.test_cfg.score_thr) >= 0:
                 check(lib.ndet_select_candidates_topk(nl, pa(bests), pa(labels), pa(boxes), (ctypes.c_int * nl)(*sizes), float(self.test_cfg.score_thr),
                                                       int(self.test_cfg.nms_pre), c_void_p(c_best.data_ptr()), c_void_p(c_lab.data_ptr()),
                                                       c_void_p(c_box.data_ptr()), c_void_p(counts.data_ptr()), st), "select_candidates_topk")
                 n_cap, k_cap = min(tot, 4096), 1024
                 bufs = self.__dict__.setdefault("_ndet_post", {})
-                key = (str(dev), n_cap)
+                stream = torch.cuda.current_stream(dev)
+                key = (str(dev), n_cap, int(stream.cuda_stream))     # one set per stream: scenes in flight do not share it
                 if key not in bufs:
                     bufs[key] = (torch.empty((n_cap,), dtype=torch.int64, device=dev), torch.empty((1,), dtype=torch.int64, device=dev),
                                  torch.empty((max(int(lib.ndet_nms_workspace_bytes(n_cap)), 8),), dtype=torch.uint8, device=dev))
@@ -223,46 +275,24 @@ class ScanNetImVoxelHeadV2(nn.Module):
                                                    c_void_p(counts.data_ptr()), nl, int(self.test_cfg.nms_pre), n_cap, float(self.test_cfg.iou_thr),
                                                    c_void_p(keep.data_ptr()), c_void_p(n_keep.data_ptr()), c_void_p(ws.data_ptr()),
                                                    c_void_p(packed_out.data_ptr()), k_cap, st), "nms_pack_detections")
-                host = packed_out.cpu()                                   # the one host sync of the scene
-                k, status = int(host[0]), int(host[2])
-                if status == 0:
-                    rows = host[4:4 + k * 9].view(k, 9)
-                    b = object.__new__(DepthInstance3DBoxes)
-                    b.tensor, b.box_dim, b.with_yaw = rows[:, :7].contiguous(), 7, False
-                    return [(b, rows[:, 7].contiguous(), rows[:, 8].to(torch.int64))]
-            # ---- general tail (more than 4096 candidates or 1024 picks, another box container): host-driven ----
-            check(lib.ndet_select_candidates(nl, pa(bests), pa(labels), pa(boxes), (ctypes.c_int * nl)(*sizes), float(self.test_cfg.score_thr),
-                                             c_void_p(c_best.data_ptr()), c_void_p(c_lab.data_ptr()), c_void_p(c_box.data_ptr()),
-                                             c_void_p(counts.data_ptr()), st), "select_candidates")
-            cnt = counts.cpu().tolist()   # host sync 1 of 2
-            pre = self.test_cfg.nms_pre
-            n = cnt[nl]
-            if pre > 0 and any(c > pre for c in cnt[:nl]):
-                # a level has more survivors than nms_pre: its top-nms_pre by score (all of them above the threshold, so the
-                # same set the reference's "top-k, then threshold" keeps); the other levels stay as compacted
-                pb, plab, pbox, off = [], [], [], 0
-                for c in cnt[:nl]:
-                    sb, sl, sx = c_best[off:off + c], c_lab[off:off + c], c_box[off:off + c]
-                    if c > pre:
-                        sb, ids = sb.topk(pre)
-                        sl, sx = sl[ids], sx[ids]
-                    pb.append(sb); plab.append(sl); pbox.append(sx)
-                    off += c
-                c_best, c_lab, c_box = torch.cat(pb), torch.cat(plab), torch.cat(pbox).contiguous()
-                n = int(c_best.shape[0])
-            if n == 0:
-                b = meta["box_type_3d"](c_box[:0], origin=(0.5, 0.5, 0.5), box_dim=6, with_yaw=False)
-                return [(b, c_best[:0], c_lab[:0])]
-            ids = aligned_3d_nms(c_box[:n], c_best[:n], c_lab[:n], self.test_cfg.iou_thr)   # host sync 2
-            k = int(ids.shape[0])
-            o_box = torch.empty((k, 6), dtype=torch.float32, device=dev)
-            o_sc = torch.empty((k,), dtype=torch.float32, device=dev)
-            o_lab = torch.empty((k,), dtype=torch.int64, device=dev)
-            if k:
-                check(lib.ndet_gather_detections(c_void_p(ids.data_ptr()), k, c_void_p(c_box.data_ptr()), c_void_p(c_best.data_ptr()),
-                                                 c_void_p(c_lab.data_ptr()), c_void_p(o_box.data_ptr()), c_void_p(o_sc.data_ptr()),
-                                                 c_void_p(o_lab.data_ptr()), st), "gather_detections")
-            return [(meta["box_type_3d"](o_box, origin=(0.5, 0.5, 0.5), box_dim=6, with_yaw=False), o_sc, o_lab)]
+                if defer:
+                    pin = bufs.setdefault(key + ("pin",), [torch.empty((4 + k_cap * 9,), dtype=torch.float32).pin_memory(), torch.cuda.Event()])
+                    pin[0].copy_(packed_out, non_blocking=True)
+                    pin[1].record(stream)
+
+                    def finish():
+                        pin[1].synchronize()                                  # the scene's one host sync, whenever the caller gets to it
+                        got = fast(pin[0].clone())
+                        if got is not None:
+                            return got
+                        with torch.cuda.stream(stream):
+                            return general()
+                    return finish
+                got = fast(packed_out.cpu())                                  # the one host sync of the scene
+                if got is not None:
+                    return got
+            res = general()
+            return (lambda: res) if defer else res
         # generic path: per-level top-k, then threshold, NMS, box conversion with library ops
         for i in range(nl):
             if bests[i].shape[0] > self.test_cfg.nms_pre > 0:
@@ -276,7 +306,8 @@ class ScanNetImVoxelHeadV2(nn.Module):
         b = torch.stack(((b[:, 0] + b[:, 3]) / 2.0, (b[:, 1] + b[:, 4]) / 2.0, (b[:, 2] + b[:, 5]) / 2.0,
                          b[:, 3] - b[:, 0], b[:, 4] - b[:, 1], b[:, 5] - b[:, 2]), dim=1)
         b = meta["box_type_3d"](b, origin=(0.5, 0.5, 0.5), box_dim=6, with_yaw=False)
-        return [(b, best[ids], lab[ids])]
+        res = [(b, best[ids], lab[ids])]
+        return (lambda: res) if defer else res
 
     # ---- training (A16) --------------------------------------------------------------------
     def loss(self, centernesses, bbox_preds, cls_scores, valid, img_metas, gt_bboxes, gt_labels):

@@ -398,3 +398,28 @@ def test_simple_test_with_evaluate_nerf_keeps_the_rendering_metrics(device):
     assert float(psnr) == float(want[0]) and float(ssim) == float(want[1]) and torch.equal(err, want[2])
     assert torch.isfinite(psnr) and 0.0 < float(ssim) < 1.0
     assert torch.equal(res[0]["labels_3d"], plain[0]["labels_3d"]) and torch.equal(res[0]["scores_3d"], plain[0]["scores_3d"])
+
+
+def test_forward_test_async_two_scenes_in_flight_equals_sequential(device):
+    """nerfdet.forward_test_async: two different scenes queued on two streams, collected one behind, repeatedly -- detections identical to
+    the synchronous forward_test of each scene (same boxes, scores, labels), including a scene without detections."""
+    det = _small_detector(device)
+    scenes = [_scene(device, s) for s in (1, 2, 3)]
+    with torch.no_grad():
+        want = [det.forward_test(img, [meta], denorm_images=dn, **rays)[0] for img, dn, meta, rays in scenes]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        torch.cuda.synchronize()
+        pend, got = [], []
+        for i in range(9):
+            img, dn, meta, rays = scenes[i % 3]
+            with torch.cuda.stream(streams[i % 2]):
+                pend.append(det.forward_test_async(img, [meta], denorm_images=dn, **rays))
+            if len(pend) == 2:
+                got.append(pend.pop(0)()[0])
+        while pend:
+            got.append(pend.pop(0)()[0])
+    assert len(got) == 9
+    for i, g in enumerate(got):
+        w_ = want[i % 3]
+        assert torch.equal(g["labels_3d"], w_["labels_3d"]) and torch.equal(g["scores_3d"], w_["scores_3d"])
+        assert torch.equal(g["boxes_3d"].tensor, w_["boxes_3d"].tensor)
