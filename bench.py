@@ -260,6 +260,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-serving", action="store_true", help="skip the extra two-scenes-in-flight loop after the timed region (profiling runs: its "
+                    "overlapped launches would enter the per-kernel averages)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the static part of the step from hipGraphs (nerfdet_amd/graphed.py); measured equal to eager "
                          "launches within 1 %% on MI355X: the step is GPU-bound, launch-ahead already hides the gaps")
@@ -342,7 +344,7 @@ def main():
         rec.spans = [s for s in rec.spans if s[0] != "k_backproject_aggregate"] + keep
     trace.recorder = None
     torch.cuda.synchronize()
-    serving = serve_in_flight(det_gpu, batch, args.steps) if not args.graph else None
+    serving = serve_in_flight(det_gpu, batch, args.steps) if not (args.graph or args.no_serving) else None
 
     if rank == 0:
         spans = rec.span_ms()
