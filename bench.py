@@ -344,7 +344,12 @@ def main():
         rec.spans = [s for s in rec.spans if s[0] != "k_backproject_aggregate"] + keep
     trace.recorder = None
     torch.cuda.synchronize()
-    serving = serve_in_flight(det_gpu, batch, args.steps) if not (args.graph or args.no_serving) else None
+    serving = None
+    if not (args.graph or args.no_serving):
+        try:
+            serving = serve_in_flight(det_gpu, batch, args.steps)
+        except Exception as e:     # the extra figure must never cost the headline line
+            print(f"serve_in_flight skipped: {type(e).__name__}: {e}", file=sys.stderr)
 
     if rank == 0:
         spans = rec.span_ms()
