@@ -423,3 +423,23 @@ def test_forward_test_async_two_scenes_in_flight_equals_sequential(device):
         w_ = want[i % 3]
         assert torch.equal(g["labels_3d"], w_["labels_3d"]) and torch.equal(g["scores_3d"], w_["scores_3d"])
         assert torch.equal(g["boxes_3d"].tensor, w_["boxes_3d"].tensor)
+
+
+def test_async_tail_falls_back_like_the_synchronous_one_when_the_device_side_tail_overflows(device):
+    """More than 1 024 picks (no suppression, score threshold 0): the device-side tail flags the overflow, and both forms -- forward_test
+    and forward_test_async's finish() on a side stream -- redo the tail on the host-driven path with the same detections."""
+    det = _small_detector(device)
+    det.bbox_head.test_cfg["iou_thr"] = 0.999
+    det.bbox_head.test_cfg["score_thr"] = 0.0
+    det.bbox_head.test_cfg["nms_pre"] = 5000
+    img, dn, meta, rays = _scene(device, 5)
+    with torch.no_grad():
+        want = det.forward_test(img, [meta], denorm_images=dn, **rays)[0]
+        s = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            fin = det.forward_test_async(img, [meta], denorm_images=dn, **rays)
+        got = fin()[0]
+    assert len(want["scores_3d"]) > 1024
+    assert torch.equal(got["labels_3d"], want["labels_3d"]) and torch.equal(got["scores_3d"], want["scores_3d"])
+    assert torch.equal(got["boxes_3d"].tensor, want["boxes_3d"].tensor)
