@@ -39,6 +39,7 @@ launch_hook = None  # bench.py: callable(flops, thunk, kernel_name) wrapping eve
 KERNEL_NAMES = {("bf16x3", 64): "k_conv_split<64,64,2,2>", ("bf16x3", 128): "k_conv_split<128,128,2,2>", ("bf16x3", 12864): "k_conv_split<128,64,2,2>",
                 ("bf16x3", 128256): "k_conv_split_ws", ("bf16x3", 3128): "k_conv_split_halo<4,2>", ("bf16x3", 3256): "k_conv_split_halo<8,2>", ("bf16x3", 3257): "k_conv_split_halo<4,4>",
                 ("f32", 64): "k_conv3d_igemm<64,64,2,2>", ("f32", 128): "k_conv3d_igemm<128,128,4,2>"}
+KERNEL_NAMES.update({("bf16x3", 100000 + t if t != 12864 else 112864): KERNEL_NAMES[("bf16x3", t)] for t in (64, 128, 12864)})   # direct-epilogue forms
 KERNEL_NAMES.update({("bf16", t): n for (a, t), n in list(KERNEL_NAMES.items()) if a == "bf16x3"})
 
 
@@ -97,7 +98,7 @@ def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: 
         else:
             tile = 64
     if splits == 0:
-        if transposed:
+        if transposed or tile >= 100000:     # (the direct-epilogue forms of the unified tiles write final values: no split-K)
             return tile, 1
         tm, tn = {12864: (128, 64), 128256: (128, 256), 3128: (128, 128), 3256: (128, 256), 3257: (128, 256)}.get(tile, (tile, tile))
         tiles = ((m + tm - 1) // tm) * ((cout + tn - 1) // tn)
@@ -105,6 +106,9 @@ def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: 
         while splits < 32 and k_iters // (splits + 1) >= 24 and tiles * (splits + 1) <= 768:
             splits += 1
     return tile, splits
+
+
+DIRECT_EPILOGUE = True     # unified bf16x3 tiles store straight from the accumulators' layout whenever they write final values
 
 
 def split_planes(pk: dict) -> torch.Tensor:
@@ -132,6 +136,10 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
             tile = 128256 if pk["cout"] > 128 else 128
         else:
             splits = min(splits, pk["cin"] // 32)
+    # unified tiles that write final values: the epilogue straight from the MFMA's C layout (no LDS staging, no barriers)
+    base = {100064: 64, 100128: 128, 112864: 12864}.get(tile, tile)
+    direct_ok = (splits == 1 and not transposed and not residual_up2 and pk["cout"] % 32 == 0 and (m + 128) * pk["cout"] * 4 < (1 << 32))
+    tile = {64: 100064, 128: 100128, 12864: 112864}[base] if (base in (64, 128, 12864) and direct_ok and DIRECT_EPILOGUE) else base
     ws = torch.empty((m * pk["cout"] * splits * 4,), dtype=torch.uint8, device=x.device) if splits > 1 else None
     i3 = lambda v: (ctypes.c_int * 3)(*v)
     st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)

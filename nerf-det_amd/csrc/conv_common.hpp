@@ -26,6 +26,8 @@ struct Conv3dParams {
     int RH, RW;           //    its H and W
     int max_order;        // bf16x3 kernels: products (pa, pb) with pa + pb <= max_order are issued -- 2: all six (fp32-class result),
                           // 0: a0*b0 only = both operands rounded to bf16, fp32 accumulate (the "bf16" arithmetic of BASELINE configs 3/5)
+    int direct = 0;       // unified bf16x3 tiles: 1 = the epilogue stores straight from the MFMA's C layout with buffer operations (no LDS staging,
+                          // no barriers; needs splits == 1, no transposed / upsampled-residual mode, Cout % 32 == 0, output < 4 GB)
     float xscale;         // fp16-pair tiles: power of two the activations are multiplied by while they are split (its inverse, and the
                           // weight scale's, are folded into `scale` by the caller)
 };

@@ -268,8 +268,42 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
     int ztap;
     conv_split_mainloop<BM, BN, WGM, WGN, ONE>(p, wsplit, lds16, acc, ztap);
 
-    // ---- epilogue: accumulators -> LDS (one wave-row of the tile at a time) -> fused row-wise stores ----
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    if (p.direct) {
+        // ---- direct epilogue: a register of a 32 x 32 tile is 32 consecutive channels of one row = one 128-byte line; residual reads and
+        // stores are buffer operations (lane part of the address in one VGPR, the register's row in the scalar offset, rows past M outside the
+        // descriptor).  No LDS staging, no barrier: the workgroup's waves drain independently while the CU's other workgroups multiply ----
+        const unsigned obytes = (unsigned)((int64_t)p.M * p.Cout * 4);
+        const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.out), 0, obytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, obytes, 0x00020000);
+#pragma unroll
+        for (int tb = 0; tb < NT; ++tb) {
+            const int co = n0 + wn * WN + tb * 32 + (lane & 31);
+            if (n0 + wn * WN + tb * 32 >= p.Cout) continue;            // Cout % 32 == 0: a 32-column tile is all inside or all outside
+            const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.scale ? p.shift[co] : 0.0f;
+#pragma unroll
+            for (int ta = 0; ta < MT; ++ta) {
+                const unsigned vo = (unsigned)(((int64_t)(m0 + wm * WM + ta * 32 + 4 * (lane >> 5)) * p.Cout + co) * 4);
+                float rr[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(((r & 3) + 8 * (r >> 2)) * p.Cout * 4));
+                    rr[r] = p.res ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rres, vo, so, 0)) : 0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(((r & 3) + 8 * (r >> 2)) * p.Cout * 4));
+                    float v = acc[ta][tb][r] * sc + sh;
+                    if (p.relu == 2) v = fmaxf(v, 0.f);
+                    v += rr[r];
+                    if (p.relu == 1) v = fmaxf(v, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, vo, so, 0);
+                }
+            }
+        }
+        return;
+    }
+    // ---- epilogue: accumulators -> LDS (one wave-row of the tile at a time) -> fused row-wise stores ----
     constexpr int CLDC = BN + 4;
     float* Cs = reinterpret_cast<float*>(lds16);   // [WM][CLDC] floats <= the operand planes
     for (int h = 0; h < WGM; ++h) {
@@ -1281,6 +1315,13 @@ static int split_launch_tile(const Conv3dParams& p, hipStream_t st, const char* 
 }
 
 int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn) {
+    p.direct = 0;
+    if (tile >= 100000 && (tile - 100000 == 64 || tile - 100000 == 128 || tile - 100000 == 12864)) {   // 100064 / 100128 / 112864: direct epilogue
+        tile -= 100000;
+        NDET_REQUIRE(!p.transposed && p.splits == 1 && !p.res_up2 && p.Cout % 32 == 0 && ((int64_t)p.M + 128) * p.Cout * 4 < ((int64_t)1 << 32),
+                     NDET_E_UNSUPPORTED, "%s: the direct epilogue needs splits == 1, a plain residual, Cout %% 32 == 0 and an output below 4 GB", fn);
+        p.direct = 1;
+    }
     const int64_t big_tiles = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     if (tile == 0) tile = (big_tiles >= 192 && p.Cout >= 128) ? 128 : 64;
     int rc;
@@ -1438,6 +1479,7 @@ static int conv_split_entry(const char* fn, int max_order, float xscale, const f
     NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
     NDET_REQUIRE((scale == nullptr) == (shift == nullptr), NDET_E_INVALID, "%s: scale and shift go together", fn);
     NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128 || tile == 12864 || tile == 128256 || tile == 3128 || tile == 3256 || tile == 3257 ||
+                                          tile == 100064 || tile == 100128 || tile == 112864 ||
                                           (xscale > 0.0f && (tile == 4128 || tile == 4256 || tile == 4257))), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
     NDET_REQUIRE(Cin % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
     NDET_REQUIRE((((uintptr_t)in | (uintptr_t)w_planes) & 15) == 0, NDET_E_UNSUPPORTED, "%s: in / weights must be 16-byte aligned", fn);

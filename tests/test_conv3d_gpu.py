@@ -421,3 +421,24 @@ def test_fused_stem_matches_torch_fp32(device, nhw, layout):
         got = stem_conv_bn_relu_maxpool(xd, conv, bn)
     assert got.shape == ref.shape
     assert float((got.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("cin,cout,nhw,k,stride,relu,use_res,tile", [(64, 256, (3, 13, 17), 1, 1, 1, True, 100064), (256, 64, (2, 12, 16), 1, 1, 1, False, 112864),
+                                                                     (128, 128, (2, 13, 17), 3, 2, 1, False, 100128), (128, 96, (2, 9, 11), 3, 1, 2, True, 100064),
+                                                                     (256, 512, (2, 9, 11), 1, 2, 0, False, 100128)])
+def test_direct_epilogue_equals_the_staged_epilogue(device, cin, cout, nhw, k, stride, relu, use_res, tile):
+    """The unified tiles' direct epilogue (stores from the MFMA's C layout through buffer operations, tile codes 100064 / 100128 / 112864)
+    against the LDS-staged one: the same values, bit for bit (ragged last tile, residual, both ReLU positions, stride 2)."""
+    from nerfdet_amd.conv3d import conv2d_nhwc, packed
+    torch.manual_seed(cin + cout + k)
+    conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=False).to(device)
+    bn = nn.BatchNorm2d(cout).eval().to(device)
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+        x = torch.randn(*nhw, cin, device=device)
+        pk = packed([conv], bn)
+        oh, ow = (nhw[1] + 2 * (k // 2) - k) // stride + 1, (nhw[2] + 2 * (k // 2) - k) // stride + 1
+        res = torch.randn(nhw[0], oh, ow, cout, device=device) if use_res else None
+        staged = conv2d_nhwc(x, pk, residual=res, relu=relu, tile=tile - 100000, splits=1)
+        direct = conv2d_nhwc(x, pk, residual=res, relu=relu, tile=tile)
+    assert torch.equal(direct, staged)

@@ -6,6 +6,7 @@ import bench
 from nerfdet_amd import conv3d
 
 w = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
+ATTR = sys.argv[2] if len(sys.argv) > 2 else "CHAIN_BOTTLENECKS"     # ab_chain.py cfg2 DIRECT_EPILOGUE: any boolean switch of nerfdet_amd.conv3d
 dev = torch.device("cuda")
 det = bench.build_model(w).to(dev)
 batch = bench.to_device(bench.synth_batch(w, 0), dev)
@@ -22,9 +23,9 @@ def run(n):
 
 with torch.no_grad():
     for flag in (True, False):
-        conv3d.CHAIN_BOTTLENECKS = flag
+        setattr(conv3d, ATTR, flag)
         run(5)
     for rep in range(4):
         for flag in (True, False):
-            conv3d.CHAIN_BOTTLENECKS = flag
-            print(f"rep {rep} chain={flag}: {run(20):.3f} ms/step", flush=True)
+            setattr(conv3d, ATTR, flag)
+            print(f"rep {rep} {ATTR}={flag}: {run(20):.3f} ms/step", flush=True)

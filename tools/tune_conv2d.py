@@ -40,7 +40,7 @@ def main():
         C3.set_arithmetic(sys.argv[1])
     if len(sys.argv) > 4:          # tune_conv2d.py <arithmetic> <n_views> <H> <W>
         LAYERS = layers_for(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
-    tiles = (64, 128, 12864, 128256, 3128, 3256, 3257) if C3.ARITHMETIC in ("bf16x3", "bf16") else (64, 128)
+    tiles = (64, 128, 12864, 128256, 3128, 3256, 3257, 100064, 100128, 112864) if C3.ARITHMETIC in ("bf16x3", "bf16") else (64, 128)
     print("arithmetic", C3.ARITHMETIC, flush=True)
     dev = torch.device("cuda")
     tot_best = tot_auto = 0.0
@@ -65,7 +65,7 @@ def main():
             if splits > k * k * (cin // 32): continue
             try:
                 t = run(tile=tile, splits=splits)
-            except (ValueError, AssertionError):
+            except Exception:
                 continue
             if best is None or t < best[0]: best = (t, tile, splits)
         print("TUNED_JSON", __import__("json").dumps(dict(key=[nhw[0]*oh*ow, cout, k*k*(cin//32), 0], tile=best[1], splits=best[2], us=best[0]*1e3, name=name)), flush=True)
