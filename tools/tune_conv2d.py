@@ -33,13 +33,25 @@ def layers_for(n, h, w):
     return out
 
 
+def first_block_layers(n, h, w):
+    """The shapes only the first block of a stage (and the FPN laterals that share their keys) has: conv1 at the previous stage's
+    resolution, the strided 1x1 downsample."""
+    out = []
+    for i, (cin, mid) in enumerate(((64, 64), (256, 128), (512, 256), (1024, 512))):
+        hi, wi = (-(-h // 4), -(-w // 4)) if i == 0 else (-(-h // (4 << (i - 1))), -(-w // (4 << (i - 1))))
+        out.append((f"l{i+1}.0.conv1 1x1 {cin}->{mid}", cin, mid, (n, hi, wi), 1, 1, False))
+        out.append((f"l{i+1}.0.ds 1x1 s{1 if i == 0 else 2} {cin}->{4 * mid}", cin, 4 * mid, (n, hi, wi), 1, 1 if i == 0 else 2, False))
+    out.append(("fpn.lat3 1x1 2048->256", 2048, 256, (n, -(-h // 32), -(-w // 32)), 1, 1, False))
+    return out
+
+
 def main():
     from nerfdet_amd import conv3d as C3
     global LAYERS
     if len(sys.argv) > 1:
         C3.set_arithmetic(sys.argv[1])
-    if len(sys.argv) > 4:          # tune_conv2d.py <arithmetic> <n_views> <H> <W>
-        LAYERS = layers_for(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+    if len(sys.argv) > 4:          # tune_conv2d.py <arithmetic> <n_views> <H> <W> [first]
+        LAYERS = (first_block_layers if len(sys.argv) > 5 else layers_for)(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
     tiles = (64, 128, 12864, 128256, 3128, 3256, 3257, 100064, 100128, 112864) if C3.ARITHMETIC in ("bf16x3", "bf16") else (64, 128)
     print("arithmetic", C3.ARITHMETIC, flush=True)
     dev = torch.device("cuda")
