@@ -66,3 +66,40 @@ def test_hand_placed_vmcnt_waits_cover_their_dma_groups():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_vmcnt.py")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:]
     assert "0 short windows" in out.stdout and "k_conv_split_ws" in out.stdout and "k_conv_split_halo" in out.stdout
+
+
+def test_training_and_fusion_eligibility_rules():
+    """Host-side decisions of round 2: which convolutions train on the MFMA kernels, when the bottleneck tail is chained, when the stem
+    kernel and the direct epilogue apply -- pure functions of module hyper-parameters and tensor metadata (no GPU needed: CPU tensors
+    are never eligible, so the rules are probed through the attributes they read)."""
+    import torch
+    from torch import nn
+    from nerfdet_amd import conv3d, conv_train
+
+    class FakeCuda:
+        """Stands in for a float32 GPU tensor: only the attributes the rules read."""
+        is_cuda, dtype = True, torch.float32
+        def __init__(self, shape):
+            self.shape = shape
+        def dim(self):
+            return len(self.shape)
+    x5, x4 = FakeCuda((1, 256, 40, 40, 16)), FakeCuda((50, 64, 60, 80))
+    assert conv_train.eligible(nn.Conv3d(256, 512, 3, 2, 1), x5) and conv_train.eligible(nn.Conv3d(256, 512, 1, 2, 0), x5)      # stride 2: round 2
+    assert conv_train.eligible(nn.Conv2d(64, 64, 3, 1, 1), x4) and not conv_train.eligible(nn.Conv2d(3, 64, 7, 2, 3), x4)         # Cin % 32
+    assert not conv_train.eligible(nn.Conv3d(256, 256, 3, 1, 0), x5) and not conv_train.eligible(nn.Conv3d(256, 256, 3, 3, 1), x5)
+    assert not conv_train.eligible(nn.Conv2d(64, 64, 3, 1, 1, groups=2), x4) and not conv_train.eligible(nn.Conv2d(64, 64, 3, 1, 2, dilation=2), x4)
+    assert conv_train.eligible_transposed(nn.ConvTranspose3d(1024, 512, 2, 2), x5) and not conv_train.eligible_transposed(nn.ConvTranspose3d(1024, 512, 3, 2), x5)
+    bn = nn.BatchNorm2d(8)
+    assert not conv_train.frozen_eval_bn(bn)                                       # training mode, trainable affine
+    bn.eval(); bn.weight.requires_grad_(False); bn.bias.requires_grad_(False)
+    assert conv_train.frozen_eval_bn(bn)
+    pk = lambda cin, cout, k, s: dict(ndim=2, cin=cin, cout=cout, kernel=(k, k), strides=(s, s), pads=(k // 2, k // 2), transposed=False, scale=1, shift=1)
+    assert conv3d.chain_ok(pk(64, 64, 3, 1), pk(64, 256, 1, 1)) and conv3d.chain_ok(pk(128, 128, 3, 2), pk(128, 512, 1, 1))
+    assert not conv3d.chain_ok(pk(256, 256, 3, 1), pk(256, 1024, 1, 1))           # the 256-channel intermediate does not fit the tile
+    assert not conv3d.chain_ok(pk(64, 64, 3, 1), pk(64, 256, 1, 2)) and not conv3d.chain_ok(pk(64, 64, 3, 1), pk(64, 100, 1, 1))
+    prev = conv3d.set_arithmetic("f32")
+    try:
+        assert not conv3d.chain_ok(pk(64, 64, 3, 1), pk(64, 256, 1, 1))           # the exact fp32-MFMA family has no chained kernel
+    finally:
+        conv3d.set_arithmetic(prev)
+    assert conv3d.choose_tiling_split(240000, 256, 2, 100064, 0) == (100064, 1)   # direct-epilogue tiles never split K
