@@ -98,7 +98,7 @@ def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: 
         else:
             tile = 64
     if splits == 0:
-        if transposed or tile >= 100000:     # (the direct-epilogue forms of the unified tiles write final values: no split-K)
+        if transposed or tile in (100064, 100128, 112864):     # (the direct-epilogue forms of the unified tiles write final values: no split-K)
             return tile, 1
         tm, tn = {12864: (128, 64), 128256: (128, 256), 3128: (128, 128), 3256: (128, 256), 3257: (128, 256)}.get(tile, (tile, tile))
         tiles = ((m + tm - 1) // tm) * ((cout + tn - 1) // tn)
