@@ -350,6 +350,12 @@ int ndet_wgrad_split(const float* x_ndhwc, int D, int H, int W, int Cin, const i
                      const uint16_t* dy_planes, int Cout, int lrow, int splits, int max_order, void* workspace, float* dw_rows,
                      void* stream);
 
+/* dY of a convolution (L output voxels x Cout, channels-last fp32) -> the bf16 planes of its channel-major rows in the layout of
+ * ndet_split_weights_bf16x3 for a (1, Cout, lrow) "weight": (lrow/32, 3, Cout, 32), zeros past L -- the "weight" operand of the
+ * weight-gradient GEMMs (ndet_wgrad_split, or ndet_conv_ndhwc_split on ndet_wgrad_rows' tap copies) in one pass; autograd of nn.Conv3d /
+ * nn.Conv2d in mmdet3d/models/necks/imvoxelnet.py:22-67,233-260 and of the ResNet / FPN layers. */
+int ndet_wgrad_dy_planes(const float* dy_rows_by_voxel, int L, int Cout, int lrow, uint16_t* planes, void* stream);
+
 /* Backward of the fused epilogue y = relu(conv * scale + shift (+ identity)) -- convolution + frozen eval-mode BatchNorm + ReLU (+ the
  * bottleneck's identity) of the trainable ResNet stages (mmdet Bottleneck.forward behind mmdet3d/models/detectors/nerfdet.py:140;
  * config: norm_eval=True, norm_cfg.requires_grad=False): d_identity = dy [y > 0] (null = not wanted), d_conv = d_identity * scale[c],

@@ -79,6 +79,7 @@ def eligible(conv: nn.Module, x: Tensor) -> bool:
             and conv.in_channels % 32 == 0)
 
 
+FUSED_DY_PLANES = True    # dy goes to the weight-gradient GEMM's bf16 planes in one pass (k_wgrad_dy_planes) instead of transpose + split
 IMPLICIT_WGRAD = True     # multi-tap weight gradients on large grids read x in place (k_wgrad_split); False: always the staged form
                           # (tap copies by k_wgrad_rows + one GEMM)
 
@@ -110,9 +111,18 @@ def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pa
     lrow = ((lo + 31) // 32) * 32                           # the kernel steps the contraction by 32; the tail is staged as zeros
     taps = k3[0] * k3[1] * k3[2]
     # dy as the GEMM's "weight" operand (Cout rows over the output grid), split into bf16 planes once
-    grows = _rows(g, (1, 1, 1), (1, 1, 1), (0, 0, 0), 0, 1, lrow)
-    pk = dict(w=grows, scale=None, shift=None, cout=cout, cin=lrow, ksize=1, stride=1, transposed=False, kernel=(1, 1), strides=(1, 1),
-              pads=(0, 0), ndim=2)
+    if FUSED_DY_PLANES and C.ARITHMETIC in ("bf16x3", "bf16"):
+        from ctypes import c_void_p
+        from . import _lib
+        planes = torch.empty((1, lrow // 32, 3, cout, 32), dtype=torch.int16, device=x.device)     # one pass: transpose + split
+        _lib.check(_lib.load().ndet_wgrad_dy_planes(c_void_p(g.data_ptr()), lo, cout, lrow, c_void_p(planes.data_ptr()),
+                                                    c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "wgrad_dy_planes")
+        pk = dict(w=planes, w_split=planes, scale=None, shift=None, cout=cout, cin=lrow, ksize=1, stride=1, transposed=False, kernel=(1, 1),
+                  strides=(1, 1), pads=(0, 0), ndim=2)
+    else:
+        grows = _rows(g, (1, 1, 1), (1, 1, 1), (0, 0, 0), 0, 1, lrow)
+        pk = dict(w=grows, scale=None, shift=None, cout=cout, cin=lrow, ksize=1, stride=1, transposed=False, kernel=(1, 1), strides=(1, 1),
+                  pads=(0, 0), ndim=2)
     if implicit is None:
         implicit = IMPLICIT_WGRAD and taps >= 9 and lo >= 16384
     if implicit and C.ARITHMETIC in ("bf16x3", "bf16") and cin % 64 == 0:

@@ -202,3 +202,59 @@ extern "C" int ndet_relu_affine_bwd(const float* dy, const float* y, const float
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// dY of a convolution, channels-last (L output voxels x Cout), straight to the weight-gradient GEMM's "weight" operand: the three bf16
+// planes of its channel-major rows, tiled per K step of 32 voxels -- (lrow/32, 3, Cout, 32), the layout of ndet_split_weights_bf16x3 --
+// with zeros past L.  One pass instead of k_wgrad_rows (transpose to fp32 rows) + k_split_weights (read them back, split): autograd of
+// nn.Conv3d / nn.Conv2d, mmdet3d/models/necks/imvoxelnet.py:22-67,233-260.  64 voxels x 64 channels per workgroup through an LDS
+// transpose; a thread then owns 16 consecutive voxels of one channel: splits them and writes 32 bytes per plane.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pk_bf16x2(float x, float y) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const b2 v = __builtin_convertvector((f2){x, y}, b2);
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_dy_planes(const float* __restrict__ g, int L, int C, int lrow, uint16_t* __restrict__ planes) {
+    __shared__ float tile[64][65];
+    const int j0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const bool cok = c0 + tx < C;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int vj = ty + 4 * i;
+        tile[vj][tx] = (j0 + vj < L && cok) ? g[(int64_t)(j0 + vj) * C + c0 + tx] : 0.0f;
+    }
+    __syncthreads();
+    const int co = c0 + tx, chunk = ty & 1, half = ty >> 1;                 // 64 channels x 2 K chunks x 2 halves of 16 voxels
+    const int kc = (j0 >> 5) + chunk;
+    if (!cok || kc * 32 >= lrow) return;
+    uint32_t o[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float a = tile[chunk * 32 + half * 16 + 2 * i][tx], b = tile[chunk * 32 + half * 16 + 2 * i + 1][tx];
+        o[0][i] = pk_bf16x2(a, b);
+        const float ra = a - __uint_as_float(o[0][i] << 16), rb = b - __uint_as_float(o[0][i] & 0xffff0000u);
+        o[1][i] = pk_bf16x2(ra, rb);
+        o[2][i] = pk_bf16x2(ra - __uint_as_float(o[1][i] << 16), rb - __uint_as_float(o[1][i] & 0xffff0000u));
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        uint4* dst = reinterpret_cast<uint4*>(planes + (((int64_t)kc * 3 + pl) * C + co) * 32 + half * 16);
+        dst[0] = make_uint4(o[pl][0], o[pl][1], o[pl][2], o[pl][3]);
+        dst[1] = make_uint4(o[pl][4], o[pl][5], o[pl][6], o[pl][7]);
+    }
+}
+
+extern "C" int ndet_wgrad_dy_planes(const float* dy_rows_by_voxel, int L, int Cout, int lrow, uint16_t* planes, void* stream) {
+    const char* fn = "ndet_wgrad_dy_planes";
+    NDET_REQUIRE(dy_rows_by_voxel && planes, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(L > 0 && Cout > 0 && lrow >= L && lrow % 32 == 0, NDET_E_INVALID, "%s: bad sizes (L=%d, lrow=%d)", fn, L, lrow);
+    NDET_REQUIRE((((uintptr_t)planes) & 15) == 0 && (Cout + 63) / 64 <= 65535, NDET_E_UNSUPPORTED, "%s: planes must be 16-byte aligned", fn);
+    hipLaunchKernelGGL(k_wgrad_dy_planes, dim3((lrow + 63) / 64, (Cout + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy_rows_by_voxel, L, Cout, lrow,
+                       planes);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
