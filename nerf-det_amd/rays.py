@@ -255,6 +255,9 @@ def render_rays_func(ray_o, ray_d, mean_volume, cov_volume, features_2D, img, aa
     return ret
 
 
+RENDER_TESTING_RAYS = 8192     # rays per pass of the render_testing walk on the GPU (a multiple of N_rand is used)
+
+
 def begin_selection(ray_batch):
     """First half of the training-time ray draw of render_ray.py:386-404: the rays WITH depth (``gt_depth > 0``; all rays when the scene has
     no depth maps), as indices into the flattened ray list, and their number.  Depends on the inputs only, so the detector takes it
@@ -304,8 +307,11 @@ def render_rays(ray_batch, mean_volume, cov_volume, features_2D, img, aabb, near
         gt_depth = gt_depth.view(-1, 1) if len(gt_depth) != 0 else None
         assert view_num * hh * ww == ray_o.shape[0]  # render_ray.py:468
         rgbs, depths = [], []
-        for i in range(0, ray_o.shape[0], N_rand):
-            ret = render_rays_func(ray_o[i:i + N_rand], ray_d[i:i + N_rand], mean_volume, cov_volume, features_2D, img, aabb,
+        # the reference walks the rays N_rand at a time (render_ray.py:470); a ray's result does not depend on its chunk mates (deterministic
+        # sampling, row-wise MLP), so on the GPU several of its chunks go through one pass: fewer, larger GEMMs
+        step = N_rand * max(1, RENDER_TESTING_RAYS // N_rand) if ray_o.is_cuda else N_rand
+        for i in range(0, ray_o.shape[0], step):
+            ret = render_rays_func(ray_o[i:i + step], ray_d[i:i + step], mean_volume, cov_volume, features_2D, img, aabb,
                                    near_far_range, N_samples, N_rand, nerf_mlp, img_meta, projector, mode, nerf_sample_view,
                                    inv_uniform, N_importance, True, is_train, white_bkgd, gt_rgb, gt_depth)
             rgbs.append(ret["outputs_coarse"]["rgb"])
