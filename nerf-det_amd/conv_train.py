@@ -176,7 +176,7 @@ class ConvS1(torch.autograd.Function):
         kernel = tuple(weight.shape[2:])
         ctx.kernel, ctx.stride = kernel, int(stride)
         w = weight.detach()
-        ctx.save_for_backward(x.detach(), w)
+        ctx.save_for_backward(x.detach().contiguous(), w)      # the backward kernels index it densely
         return _conv(x.detach().contiguous(), _train_pack(w, kernel, False, int(stride)))
 
     @staticmethod
@@ -214,7 +214,7 @@ class ConvAffineAct(torch.autograd.Function):
         res = None if residual is None else residual.detach().contiguous()
         y = (C.conv3d_ndhwc if pk["ndim"] == 3 else C.conv2d_nhwc)(x.detach().contiguous(), pk, residual=res, relu=1 if relu else 0)
         ctx.kernel, ctx.stride, ctx.relu, ctx.has_res = kernel, int(stride), bool(relu), residual is not None
-        ctx.save_for_backward(x.detach(), w, scale, y if relu else None)
+        ctx.save_for_backward(x.detach().contiguous(), w, scale, y if relu else None)      # the backward kernels index it densely
         return y
 
     @staticmethod
@@ -270,7 +270,7 @@ class ConvT2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         w = weight.detach()
-        ctx.save_for_backward(x.detach(), w)
+        ctx.save_for_backward(x.detach().contiguous(), w)      # the backward kernels index it densely
         pk = dict(w=C.pack_weight(w, True), scale=None, shift=None, cout=int(w.shape[1]), cin=int(w.shape[0]), ksize=2, stride=2, transposed=True,
                   kernel=(2, 2, 2), strides=(2, 2, 2), pads=(0, 0, 0), ndim=3)
         return C.conv3d_ndhwc(x.detach().contiguous(), pk)
