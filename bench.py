@@ -25,8 +25,6 @@ from __future__ import annotations
 import argparse
 import json
 import os
-import socket
-import subprocess
 import sys
 import time
 
@@ -36,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4-copy ceiling)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec; the ceiling a float4 copy reaches on the box is measured live (hbm_copy_ceiling)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA peak (v_mfma_f32_16x16x4_f32), = fp32 vector peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
@@ -67,7 +65,8 @@ def traffic_of(traffic, name):
     """Per-launch bytes of kernel ``name`` ("k_conv_split_halo<4,4>") in a {profile kernel name: bytes} table; the profile's names carry
     every template argument ("k_conv_split_halo<4,4,0>"), so the match is on the name up to its closing bracket."""
     stem = name[:-1] if name.endswith(">") else name
-    return next((v for k, v in traffic.items() if k == name or k.startswith(stem + ",") or k.startswith(stem + "<") or k.startswith(stem + ">")), None)
+    return next((v for k, v in traffic.items() if k == name or k.startswith(stem + ",") or k.startswith(stem + "<") or k.startswith(stem + ">")
+                 or (not name.endswith(">") and k.startswith(stem + "_packed"))), None)    # K2 / K4 run as "<name>_packed<...>" at cm % 4 == 0
 
 
 def measured_traffic(workload):
@@ -141,6 +140,7 @@ def cpu_baseline(w, det_cpu, batch, scenes=5, warmups=2):
     the oracle (PyTorch-CPU restatement: materialised per-view volume, Python per-view loops, sequential NMS) for the
     volumetric path, 3D neck, head and NMS, plus the same ResNet+FPN modules run by PyTorch-CPU."""
     from oracle import nerfdet_oracle as O
+    O.PINNED_ARITHMETIC = False   # time the reference's own library calls (torch.bmm), not the oracle's host-independent emulation of them
     cores = min(os.cpu_count() or 1, 32)  # measured on the GPU box: 16-32 threads is the knee (256 is 50x slower)
     torch.set_num_threads(cores)
     meta = batch["img_metas"][0]
@@ -174,33 +174,9 @@ def cpu_baseline(w, det_cpu, batch, scenes=5, warmups=2):
 
 def launch_ranks(args) -> int:
     """``python bench.py --gpus N`` without a launcher: start the N ranks as fresh child processes (this parent never touches the
-    GPU), rank 0 inherits stdout and prints the JSON line."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    try:
-        while procs:
-            for p in list(procs):
-                code = p.poll()
-                if code is None:
-                    continue
-                procs.remove(p)
-                if code != 0:
-                    rc = rc or code
-                    for q in procs:      # a rank died: the others would wait in the barrier forever
-                        q.terminate()
-            time.sleep(0.05)
-    finally:
-        for p in procs:
-            p.kill()
-    return rc
+    GPU), rank 0 inherits stdout and prints the JSON line; a rank that dies takes the others down (nerfdet_amd.dist.launch_local_ranks)."""
+    from nerfdet_amd.dist import launch_local_ranks
+    return launch_local_ranks(__file__, sys.argv[1:], args.gpus)
 
 
 def dry_run(args, rank, world):
@@ -225,6 +201,34 @@ def dry_run(args, rank, world):
                           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "dry_run": True}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def hbm_copy_ceiling(device, mib=1024, reps=20):
+    """Empirical HBM ceiling: the library's float4 copy kernel (ndet_hbm_copy) on two ``mib``-MiB buffers -- far beyond the
+    256 MB Infinity Cache --, HIP events on the launch stream, best and median of ``reps`` launches.  GB/s counts read + write."""
+    from ctypes import c_void_p
+    from nerfdet_amd import _lib
+    lib = _lib.load()
+    n = mib * (1 << 20) // 4
+    src = torch.empty(n, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    stream = torch.cuda.current_stream(device)
+    sp = c_void_p(stream.cuda_stream)
+
+    def launch():
+        _lib.check(lib.ndet_hbm_copy(c_void_p(src.data_ptr()), c_void_p(dst.data_ptr()), n, sp), "hbm_copy")
+    for _ in range(3):
+        launch()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record(stream)
+        launch()
+        b.record(stream)
+    torch.cuda.synchronize(device)
+    assert torch.equal(dst[:4096], src[:4096]) and torch.equal(dst[-4096:], src[-4096:])
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    gbs = [2 * 4 * n / (m * 1e-3) / 1e9 for m in ms]
+    return {"best": gbs[0], "median": gbs[len(gbs) // 2], "mib_per_buffer": mib, "launches": reps}
 
 
 def serve_in_flight(det, batch, steps, n_streams=2):
@@ -323,14 +327,18 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ticks = [t0]
     for i in range(args.steps):
         state["step"] = i
         res = step()
+        ticks.append(time.perf_counter())     # a step hands back host-side detections: it has ended when it returns
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
     from nerfdet_amd.dist import max_over_ranks
     dt = max_over_ranks(dt, device)
+    per_step = sorted((b - a) * 1e3 for a, b in zip(ticks, ticks[1:]))
+    pct = lambda q: per_step[min(len(per_step) - 1, int(round(q * (len(per_step) - 1))))]
 
     n_conv_steps = len([i for i in range(args.steps) if i % 4 == 0])
     if args.graph:  # per-kernel breakdown from a few eager steps outside the timed region (events cannot sit inside a graph)
@@ -351,6 +359,7 @@ def main():
         except Exception as e:     # the extra figure must never cost the headline line
             print(f"serve_in_flight skipped: {type(e).__name__}: {e}", file=sys.stderr)
 
+    copy = hbm_copy_ceiling(device) if rank == 0 else None
     if rank == 0:
         spans = rec.span_ms()
         stages = rec.stage_ms()
@@ -393,7 +402,7 @@ def main():
             ach = abytes / (avg * 1e-3) / 1e9
             tr = traffic_of(traffic, name)   # profile names carry template arguments
             return {"kernel": label, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": tr, "traffic_source": None if tr is None else
+                    "frac_of_copy_ceiling": ach / copy["best"], "traffic": tr, "traffic_source": None if tr is None else
                     f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                     "algorithmic_bytes": abytes, "avg_launch_ms": avg, "median_launch_ms": ms[len(ms) // 2], "launches": len(ms)}
 
@@ -405,6 +414,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "median_ms": pct(0.5), "p10_ms": pct(0.1), "p90_ms": pct(0.9),
+            "hbm_copy_ceiling_gbs": copy["best"], "hbm_copy_ceiling": copy,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -437,7 +448,8 @@ def main():
                          "kernel": f"convolution launches whose algorithmic intensity is below the ridge point ({ridge:.0f} FLOP/B): the ResNet "
                                    f"1x1 layers and the stride-2 / small-K layers -- HBM is the roof that binds them",
                          "bound": "hbm", "achieved": mem_bytes / (mem_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": mem_bytes / (mem_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "frac": mem_bytes / (mem_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_of_copy_ceiling": mem_bytes / (mem_ms * 1e-3) / 1e9 / copy["best"], "traffic": None,
                          "algorithmic_bytes_per_step": mem_bytes / n_conv_steps, "launches_per_step": len(mem) / n_conv_steps,
                          "total_ms_per_step": mem_ms / n_conv_steps},
             "roofline_projection": hbm_line("k_backproject_aggregate", "k_backproject_aggregate (K1: fused backproject + view mean/count + alpha gating)",

@@ -48,6 +48,12 @@ int ndet_get_points(float* points, int nx, int ny, int nz, const float* voxel_si
  * want one pixel's channels contiguous (SURVEY.md section 7 "Layout").  No reference counterpart. */
 int ndet_nchw_to_nhwc(const float* src, float* dst, int n, int c, int hw, void* stream);
 
+/* Measurement aid: dst[i] = src[i] with 16-byte accesses, grid-stride over 8 192 workgroups.  Its rate (2 * 4 * n_floats / time) is the
+ * empirical HBM ceiling bench.py prices the gather kernels against, next to the 8 TB/s specification (SURVEY.md 8d "the builder must
+ * also report an empirical copy-kernel ceiling"; the reference's harness has no counterpart, tools/benchmark.py:63-89 times the model only).
+ * Pointers 16-byte aligned, n_floats % 4 == 0. */
+int ndet_hbm_copy(const float* src, float* dst, int64_t n_floats, void* stream);
+
 /* A3 (exact API form). Replaces backproject(), nerfdet.py:393-420 (depth=None).
  * features: element (v,c,y,x) at v*sv + c*sc + y*sy + x*sx (floats) -- any layout.
  * points (3,N); projection (n_views,3,4).  Outputs the reference's materialised tensors:

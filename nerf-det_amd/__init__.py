@@ -17,12 +17,16 @@ Layout (only what the path needs):
   eval.py           indoor mAP@0.25/0.5
   pipeline.py       input contract: scene cameras, view sampling, normalised views + target rays on the GPU
   synth.py          deterministic synthetic ScanNet-shaped scenes for bench.py
+  checkpoint.py     load_checkpoint / save_checkpoint in mmcv's file layout (meta + state_dict, module. prefix, key report)
+  hostmath.py       the camera-matrix products in a fixed fp32 operation order (host independent)
 """
+__version__ = "0.3.0"
+
 from . import _lib  # noqa: F401
 from ._lib import LIB_PATH, NdetError  # noqa: F401
 
 _SUBMODULES = ("ops", "rays", "nms", "conv3d", "conv_tuning", "autograd", "volume", "radiance_field", "nerf_mlp", "backbone", "neck3d",
-               "head", "losses", "boxes", "detector", "registry", "config", "presets", "graphed", "dist", "eval", "pipeline", "synth")
+               "head", "losses", "boxes", "detector", "registry", "config", "presets", "graphed", "dist", "eval", "pipeline", "synth", "checkpoint", "hostmath", "train", "datasets")
 __all__ = list(_SUBMODULES) + ["LIB_PATH", "NdetError"]
 
 

@@ -24,6 +24,7 @@ SIGNATURES = {
     "ndet_last_error": ([], c_char_p),
     "ndet_get_points": ([_P, c_int, c_int, c_int, _F3, _F3, _P], c_int),
     "ndet_nchw_to_nhwc": ([_P, _P, c_int, c_int, c_int, _P], c_int),
+    "ndet_hbm_copy": ([_P, _P, c_int64, _P], c_int),
     "ndet_backproject": ([_P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, _P, c_int, _P, _P, _P, _P], c_int),
     "ndet_backproject_aggregate": ([_P, c_int, c_int, c_int, c_int, c_int64, c_int64, _P, c_int, _P, _P, _P, c_int, _P, _P], c_int),
     "ndet_density_features": ([_P, c_int, c_int, c_int, c_int, c_int64, c_int64, _P, _P, c_int, c_int, c_int64, c_int64,

@@ -100,8 +100,8 @@ class ResNet(nn.Module):
     def init_weights(self, pretrained=None):
         """``torchvision://resnet50`` is a network fetch (unavailable offline); a local path loads."""
         if isinstance(pretrained, str) and not pretrained.startswith(("torchvision://", "http")):
-            sd = torch.load(pretrained, map_location="cpu")
-            self.load_state_dict(sd.get("state_dict", sd), strict=False)
+            from .checkpoint import load_checkpoint
+            load_checkpoint(self, pretrained, map_location="cpu", strict=False)
             return
         for m in self.modules():
             if isinstance(m, nn.Conv2d):

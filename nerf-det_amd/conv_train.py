@@ -176,8 +176,9 @@ class ConvS1(torch.autograd.Function):
         kernel = tuple(weight.shape[2:])
         ctx.kernel, ctx.stride = kernel, int(stride)
         w = weight.detach()
-        ctx.save_for_backward(x.detach().contiguous(), w)      # the backward kernels index it densely
-        return _conv(x.detach().contiguous(), _train_pack(w, kernel, False, int(stride)))
+        xc = x.detach().contiguous()                            # the backward kernels index it densely
+        ctx.save_for_backward(xc, w)
+        return _conv(xc, _train_pack(w, kernel, False, int(stride)))
 
     @staticmethod
     def backward(ctx, g):
@@ -212,9 +213,10 @@ class ConvAffineAct(torch.autograd.Function):
         pk = _train_pack(w, kernel, False, int(stride))
         pk["scale"], pk["shift"] = scale, shift
         res = None if residual is None else residual.detach().contiguous()
-        y = (C.conv3d_ndhwc if pk["ndim"] == 3 else C.conv2d_nhwc)(x.detach().contiguous(), pk, residual=res, relu=1 if relu else 0)
+        xc = x.detach().contiguous()                            # the backward kernels index it densely
+        y = (C.conv3d_ndhwc if pk["ndim"] == 3 else C.conv2d_nhwc)(xc, pk, residual=res, relu=1 if relu else 0)
         ctx.kernel, ctx.stride, ctx.relu, ctx.has_res = kernel, int(stride), bool(relu), residual is not None
-        ctx.save_for_backward(x.detach().contiguous(), w, scale, y if relu else None)      # the backward kernels index it densely
+        ctx.save_for_backward(xc, w, scale, y if relu else None)
         return y
 
     @staticmethod
@@ -249,7 +251,9 @@ def frozen_eval_bn(bn: nn.Module) -> bool:
 def conv_bn_act(conv: nn.Module, bn: nn.Module, x: Tensor, relu: bool = True, residual: Tensor = None) -> Tensor:
     """``act(bn(conv(x)) + residual)`` for a logical (B,C,H,W) tensor.  With an eligible convolution and a frozen eval-mode BatchNorm the
     whole expression is one launch (ConvAffineAct); anything else is evaluated op by op."""
-    if torch.is_grad_enabled() and isinstance(conv, nn.Conv2d) and conv.bias is None and eligible(conv, x) and frozen_eval_bn(bn):
+    # Cout % 4: the backward's elementwise pass (ndet_relu_affine_bwd) works on channel quads
+    if (torch.is_grad_enabled() and isinstance(conv, nn.Conv2d) and conv.bias is None and conv.out_channels % 4 == 0 and eligible(conv, x)
+            and frozen_eval_bn(bn)):
         scale, shift = C.bn_affine(bn)
         xb = x.permute(0, 2, 3, 1)
         rb = None if residual is None else residual.permute(0, 2, 3, 1)
@@ -270,10 +274,11 @@ class ConvT2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         w = weight.detach()
-        ctx.save_for_backward(x.detach().contiguous(), w)      # the backward kernels index it densely
+        xc = x.detach().contiguous()                            # the backward kernels index it densely
+        ctx.save_for_backward(xc, w)
         pk = dict(w=C.pack_weight(w, True), scale=None, shift=None, cout=int(w.shape[1]), cin=int(w.shape[0]), ksize=2, stride=2, transposed=True,
                   kernel=(2, 2, 2), strides=(2, 2, 2), pads=(0, 0, 0), ndim=3)
-        return C.conv3d_ndhwc(x.detach().contiguous(), pk)
+        return C.conv3d_ndhwc(xc, pk)
 
     @staticmethod
     def backward(ctx, g):

@@ -18,7 +18,7 @@ void ndet_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int ndet_version(void) { return 102; }
+extern "C" int ndet_version(void) { return 103; }
 extern "C" const char* ndet_last_error(void) { return g_err; }
 
 #define VOX_PER_TILE 16  // one workgroup = 4 waves x 4 voxels = 16 consecutive voxels (one z column at Z=16)
@@ -95,6 +95,28 @@ extern "C" int ndet_nchw_to_nhwc(const float* src, float* dst, int n, int c, int
     dim3 grid((hw + 31) / 32, (c + 31) / 32, n);
     hipLaunchKernelGGL(k_nchw_to_nhwc, grid, dim3(256), 0, (hipStream_t)stream, src, dst, c, hw);
     NDET_CHECK_LAUNCH("ndet_nchw_to_nhwc");
+    return NDET_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// measurement aid: the float4 copy whose rate is the empirical HBM ceiling the gather kernels are priced against
+// ------------------------------------------------------------------------------------------
+typedef float ndet_f4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy_float4(const ndet_f4v* __restrict__ src, ndet_f4v* __restrict__ dst, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+extern "C" int ndet_hbm_copy(const float* src, float* dst, int64_t n_floats, void* stream) {
+    NDET_REQUIRE(src && dst, NDET_E_INVALID, "ndet_hbm_copy: null pointer");
+    NDET_REQUIRE(n_floats > 0 && n_floats % 4 == 0, NDET_E_INVALID, "ndet_hbm_copy: the length must be a positive multiple of 4 floats");
+    NDET_REQUIRE(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, NDET_E_INVALID, "ndet_hbm_copy: pointers must be 16-byte aligned");
+    const int64_t n4 = n_floats / 4;
+    const int64_t blocks = (n4 + 255) / 256;
+    const int grid = (int)(blocks < 256 * 32 ? blocks : 256 * 32);      // 32 workgroups per CU, grid-stride
+    hipLaunchKernelGGL(k_copy_float4, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const ndet_f4v*)src, (ndet_f4v*)dst, n4);
+    NDET_CHECK_LAUNCH("ndet_hbm_copy");
     return NDET_OK;
 }
 

@@ -10,7 +10,8 @@ builds and a ScanNet-format scene directory runs end to end:
   LoadAnnotations3D        pipelines/loading.py:397 (the two fields the path uses)
   DefaultFormatBundle3D, Collect3D   pipelines/formating.py:33-117,186-207,237-295 (tensors instead of DataContainers: batch = 1)
   LoadImageFromFile, Resize, Normalize, Pad   mmdet 2.10 / mmcv transforms, third-party and absent from the tree: restated from their
-                           documented behaviour with PIL (cv2 is not installed) -- parity unpinned.
+                           documented behaviour (cv2 is not installed; PIL only decodes files; resampling is :func:`imresize_linear`, cv2.INTER_LINEAR's
+                           two-tap geometry and fixed-point rounding) -- parity unpinned.
 
 This is the reference's per-sample CPU flow (one data-loader worker per GPU, config:134).  The GPU-resident fast path for frames
 already decoded to the device is nerfdet_amd.pipeline.MultiViewPipeline (two kernel launches per scene); both produce the batch
@@ -66,16 +67,58 @@ class LoadImageFromFile:
         return results
 
 
+def imresize_linear(img: np.ndarray, size_wh) -> np.ndarray:
+    """``mmcv.imresize(img, (w, h))`` = ``cv2.resize(..., interpolation=cv2.INTER_LINEAR)``: two taps per axis at half-pixel centres,
+    NO antialiasing however large the reduction (a 968x1296 ScanNet frame goes to 239x320 with 2x2 taps; Pillow's BILINEAR would average
+    ~4x4 and smear invalid zero depths into their neighbours).  Geometry as in OpenCV's ``resize.cpp``: ``f = (d + 0.5) * (src / dst) - 0.5``
+    in float, ``s = floor(f)``, taps clamped at the borders.  uint8 images use its 11-bit fixed-point weights and two-stage rounding,
+    floating images are interpolated in their own precision.  cv2 / mmcv are absent from the image: restated from the published
+    algorithm, parity unpinned (the fixed-point form differs from exact arithmetic by at most one grey level)."""
+    nw, nh = int(size_wh[0]), int(size_wh[1])
+    h, w = img.shape[:2]
+    if (nw, nh) == (w, h):
+        return img.copy()
+
+    def taps(n_dst, n_src):
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * (n_src / n_dst) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = f - s.astype(np.float32)
+        lo = s < 0
+        f[lo], s[lo] = 0.0, 0
+        hi = s >= n_src - 1
+        f[hi], s[hi] = 0.0, n_src - 1
+        return s, np.minimum(s + 1, n_src - 1), f
+    x0, x1, fx = taps(nw, w)
+    y0, y1, fy = taps(nh, h)
+    src = img.reshape(h, w, -1)
+    if img.dtype == np.uint8:
+        ax1 = np.rint(fx * 2048.0).astype(np.int64)[None, :, None]
+        ax0 = np.rint((1.0 - fx) * 2048.0).astype(np.int64)[None, :, None]
+        by1 = np.rint(fy * 2048.0).astype(np.int64)[:, None, None]
+        by0 = np.rint((1.0 - fy) * 2048.0).astype(np.int64)[:, None, None]
+        rows = src.astype(np.int64)
+        hor = rows[:, x0] * ax0 + rows[:, x1] * ax1                                # (h, nw, c), scaled by 2^11
+        out = ((((by0 * (hor[y0] >> 4)) >> 16) + ((by1 * (hor[y1] >> 4)) >> 16) + 2) >> 2)
+        out = np.clip(out, 0, 255).astype(np.uint8)
+    else:
+        ft = np.float64 if img.dtype == np.float64 else np.float32
+        rows = src.astype(ft)
+        ax1 = fx.astype(ft)[None, :, None]
+        by1 = fy.astype(ft)[:, None, None]
+        hor = rows[:, x0] * (1 - ax1) + rows[:, x1] * ax1
+        out = (hor[y0] * (1 - by1) + hor[y1] * by1).astype(img.dtype if img.dtype.kind == "f" else ft)
+    return out.reshape((nh, nw) + img.shape[2:])
+
+
 @PIPELINES.register_module()
 class Resize:
     """``Resize(img_scale=(w, h), keep_ratio=True)``: the largest rescale that fits the long edge into max(img_scale) and the short
-    edge into min(img_scale) (mmcv.imrescale), bilinear."""
+    edge into min(img_scale) (mmcv.imrescale), bilinear in cv2's sense (:func:`imresize_linear`)."""
 
     def __init__(self, img_scale=None, keep_ratio: bool = True, **kw):
         self.img_scale, self.keep_ratio = tuple(img_scale), keep_ratio
 
     def __call__(self, results):
-        from PIL import Image
         img = results["img"]
         h, w = img.shape[:2]
         if self.keep_ratio:
@@ -83,10 +126,7 @@ class Resize:
             nw, nh = int(w * s + 0.5), int(h * s + 0.5)
         else:
             nw, nh = self.img_scale
-        if img.ndim == 2:
-            out = np.asarray(Image.fromarray(img.astype(np.float32), mode="F").resize((nw, nh), Image.BILINEAR))
-        else:
-            out = np.asarray(Image.fromarray(img.astype(np.uint8)).resize((nw, nh), Image.BILINEAR))
+        out = imresize_linear(img, (nw, nh))
         results.update(img=out, img_shape=out.shape, pad_shape=out.shape, scale_factor=np.array([nw / w, nh / h, nw / w, nh / h], dtype=np.float32),
                        keep_ratio=self.keep_ratio)
         return results
@@ -161,8 +201,8 @@ class MultiViewPipeline:
         name = info["filename"]
         if name.endswith(".npy"):
             return np.load(name)
-        d = np.asarray(Image.open(name)) / 1000
-        return np.asarray(Image.fromarray(d.astype(np.float32), mode="F").resize((shape_hw[1], shape_hw[0]), Image.BILINEAR))
+        d = np.asarray(Image.open(name)) / 1000          # float64, as multi_view.py:102-104 hands it to mmcv.imresize
+        return imresize_linear(d, (shape_hw[1], shape_hw[0]))
 
     def __call__(self, results):
         assert "pts_filename" not in results, "the point-cloud branch of MultiViewPipeline is not on the nerfdet path"

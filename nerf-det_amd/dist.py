@@ -5,6 +5,10 @@ with no data-path collective; the only exchanges are the result gather at the en
 from __future__ import annotations
 
 import os
+import socket
+import subprocess
+import sys
+import time
 from typing import Callable, List, Sequence
 
 import torch
@@ -74,3 +78,34 @@ def max_over_ranks(seconds: float, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def launch_local_ranks(script: str, argv: Sequence[str], n: int) -> int:
+    """``python script --gpus N`` without an external launcher: start the N ranks of one node as fresh child processes (the parent never
+    touches the GPU), 127.0.0.1 rendezvous on a free port, rank 0 inherits stdout.  The first rank that exits non-zero takes the others
+    down with it (they would wait in a collective forever); returns that exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in procs:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            p.kill()
+    return rc

@@ -276,17 +276,24 @@ class ScanNetImVoxelHeadV2(nn.Module):
                                                    c_void_p(keep.data_ptr()), c_void_p(n_keep.data_ptr()), c_void_p(ws.data_ptr()),
                                                    c_void_p(packed_out.data_ptr()), k_cap, st), "nms_pack_detections")
                 if defer:
-                    pin = bufs.setdefault(key + ("pin",), [torch.empty((4 + k_cap * 9,), dtype=torch.float32).pin_memory(), torch.cuda.Event()])
+                    # every handle owns its pinned landing buffer + event until it is collected: a scene queued on the same stream before
+                    # the previous handle's finish() ran must not overwrite that scene's picks.  Collected pairs return to a free list.
+                    free = bufs.setdefault(("pinned-free", k_cap), [])
+                    pin = free.pop() if free else [torch.empty((4 + k_cap * 9,), dtype=torch.float32).pin_memory(), torch.cuda.Event()]
                     pin[0].copy_(packed_out, non_blocking=True)
                     pin[1].record(stream)
+                    state = {"res": None}
 
                     def finish():
-                        pin[1].synchronize()                                  # the scene's one host sync, whenever the caller gets to it
-                        got = fast(pin[0].clone())
-                        if got is not None:
-                            return got
-                        with torch.cuda.stream(stream):
-                            return general()
+                        if state["res"] is None:                                  # a handle may be collected more than once
+                            pin[1].synchronize()                                  # the scene's one host sync, whenever the caller gets to it
+                            got = fast(pin[0].clone())
+                            free.append(pin)
+                            if got is None:
+                                with torch.cuda.stream(stream):
+                                    got = general()
+                            state["res"] = got
+                        return state["res"]
                     return finish
                 got = fast(packed_out.cpu())                                  # the one host sync of the scene
                 if got is not None:
@@ -333,8 +340,9 @@ class ScanNetImVoxelHeadV2(nn.Module):
         val = torch.cat([v.permute(1, 2, 3, 0).reshape(-1) for v in valids])
         ctr_t, box_t, labels = ctr_t.to(dev), box_t.to(dev), labels.to(dev)
         pts = torch.cat(pts_l)
-        if ctr.is_cuda:
-            return self._losses_masked(ctr, reg, cls, val, pts, ctr_t, box_t, labels)
+        from .losses import AxisAlignedIoULoss
+        if ctr.is_cuda and type(self.loss_bbox) is AxisAlignedIoULoss and self.loss_bbox.reduction == "mean":
+            return self._losses_masked(ctr, reg, cls, val, pts, ctr_t, box_t, labels)     # (another loss_bbox: the gathered form below)
         pos = torch.nonzero(torch.logical_and(labels >= 0, val)).reshape(-1)
         n_pos = torch.tensor(len(pos), dtype=torch.float, device=dev)
         n_pos = max(_reduce_mean(n_pos), 1.0)

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib, trace
+from .hostmath import matmul_fma_chain
 from ._lib import NDET_LAYOUT_CN, NDET_LAYOUT_NC, check, float3
 
 Tensor = torch.Tensor
@@ -41,14 +42,14 @@ def _f32c(t: Tensor) -> Tensor:
 # --------------------------------------------------------------------------------------------
 # A1
 # --------------------------------------------------------------------------------------------
-_STAGING = {}   # (n_views, device) -> [ring of pinned (n_views,3,4) buffers, next slot]
+_STAGING = {}   # (shape, dtype, device) -> [ring of pinned buffers, next slot]
 
 
 def _upload_async(host: Tensor, device) -> Tensor:
     """H2D copy that does not stall the host: through a small ring of pinned staging buffers allocated once (a pageable
     copy waits for the stream to drain -- ~200 queued backbone launches at this point of the step; pinning per call costs
     more than the stall)."""
-    key = (tuple(host.shape), str(device))
+    key = (tuple(host.shape), host.dtype, str(device))
     ring = _STAGING.get(key)
     if ring is None:
         ring = _STAGING[key] = [[[torch.empty(host.shape, dtype=host.dtype).pin_memory(), None] for _ in range(8)], 0]
@@ -66,12 +67,12 @@ def _upload_async(host: Tensor, device) -> Tensor:
 def compute_projection(img_meta: dict, stride: int, device=None) -> Tensor:
     """(n_views,3,4) pixel projections ``K' @ E[:3]`` (nerfdet.py:363-378, angles=None).
 
-    50 3x4 matrices: built on the host in the reference's fp32 op order (one tiny product per view, as the reference does:
-    batching them changes the library kernel -- and on a many-core host wakes its thread pool), one asynchronous H2D copy."""
+    50 3x4 matrices: built on the host in the fp32 op order the reference's BLAS call has in the build container (hostmath.py: the
+    result does not depend on the host's library or thread pool), one asynchronous H2D copy."""
     k = torch.tensor(np.asarray(img_meta["lidar2img"]["intrinsic"], dtype=np.float32)[:3, :3])
     k[:2] /= img_meta["ori_shape"][0] / (img_meta["img_shape"][0] / stride)
-    ext = torch.from_numpy(np.stack([np.asarray(e, dtype=np.float32) for e in img_meta["lidar2img"]["extrinsic"]]))
-    proj = torch.stack([k @ e[:3] for e in ext])
+    ext = np.stack([np.asarray(e, dtype=np.float32)[:3] for e in img_meta["lidar2img"]["extrinsic"]])
+    proj = torch.from_numpy(matmul_fma_chain(k.numpy()[None], ext))
     if device is None:
         return proj
     return _upload_async(proj, device) if torch.device(device).type == "cuda" else proj.to(device)

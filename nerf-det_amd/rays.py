@@ -13,6 +13,7 @@ import torch
 
 from . import _lib, ops, trace
 from ._lib import check
+from .hostmath import matmul_mul_add
 
 Tensor = torch.Tensor
 rng = np.random.RandomState(234)  # render_ray.py:20 -- module-global stream used for ray selection
@@ -45,7 +46,7 @@ def _camera_matrices(train_cameras: Tensor) -> Tuple[Tensor, float, float]:
     cams = train_cameras.detach().to("cpu", torch.float32)
     k = cams[:, 2:18].reshape(-1, 4, 4)
     e = cams[:, -16:].reshape(-1, 4, 4)
-    ke = k.bmm(e)[:, :3, :].contiguous()
+    ke = torch.from_numpy(matmul_mul_add(k.numpy(), e.numpy())[:, :3, :].copy())     # = k.bmm(e), in a host-independent op order
     return ke, float(cams[0, 0]), float(cams[0, 1])
 
 

@@ -30,6 +30,39 @@ import torch.nn.functional as F
 
 Tensor = torch.Tensor
 
+# The reference leaves three small products to the host's BLAS (``intrinsic @ extrinsic[:3]``, nerfdet.py:377; ``torch.bmm(projection,
+# points)``, nerfdet.py:398), whose last bit depends on the kernel that BLAS picks for the CPU it runs on -- and ``.round()`` turns a last
+# bit into a neighbouring pixel (3 of 25 600 voxels on the GPU box's CPU).  With PINNED_ARITHMETIC the oracle evaluates them
+# in the order MKL uses in the build container -- a k-ordered chain of fp32 FMAs -- emulated in integer-exact numpy, so that it returns the
+# REFERENCE-AS-RUN-IN-THE-BUILD-CONTAINER on any host: that is what the golden fixtures hold (tests/golden/fullsize_cfg*.npz were written
+# by the real reference there) and tests/test_oracle_golden.py checks the emulation against ``torch.bmm`` itself where it runs.
+# bench.py's cpu_baseline leg switches it off (the baseline times the reference's own library calls).
+PINNED_ARITHMETIC = True
+
+
+def fma_chain_matmul(a, b) -> np.ndarray:
+    """(...,m,K) @ (...,K,n) in fp32 as ``fma(a_K-1, b_K-1, ... fma(a_1, b_1, a_0 * b_0))``, every step rounded ONCE.
+
+    A product of two fp32 numbers is exact in fp64; the sum with the fp32 accumulator is made exact by TwoSum and rounded to odd
+    in fp64, after which the single rounding to fp32 equals the hardware FMA's (53 >= 24 + 2 bits)."""
+    a = np.asarray(a, dtype=np.float32)
+    b = np.asarray(b, dtype=np.float32)
+    kdim = a.shape[-1]
+    assert b.shape[-2] == kdim
+    acc = (a[..., :, 0, None].astype(np.float64) * b[..., None, 0, :].astype(np.float64)).astype(np.float32)
+    for k in range(1, kdim):
+        p = a[..., :, k, None].astype(np.float64) * b[..., None, k, :].astype(np.float64)
+        c = acc.astype(np.float64)
+        s = p + c
+        t = s - p
+        err = (p - (s - t)) + (c - t)                       # p + c == s + err exactly
+        bits = s.view(np.int64)
+        fix = (err != 0) & ((bits & 1) == 0)
+        away = (err > 0) == (s > 0)
+        bits = np.where(fix, np.where(away, bits + 1, bits - 1), bits)
+        acc = bits.view(np.float64).astype(np.float32)
+    return acc
+
 
 # --------------------------------------------------------------------------- #
 # A1  camera matrices
@@ -45,6 +78,9 @@ def compute_projection(img_meta: dict, stride: int) -> Tensor:
     k = torch.tensor(np.asarray(img_meta["lidar2img"]["intrinsic"])[:3, :3])
     ratio = img_meta["ori_shape"][0] / (img_meta["img_shape"][0] / stride)
     k[:2] /= ratio
+    if PINNED_ARITHMETIC:
+        ext = np.stack([np.asarray(e, dtype=np.float32)[:3] for e in img_meta["lidar2img"]["extrinsic"]])
+        return torch.from_numpy(fma_chain_matmul(k.numpy()[None], ext))
     mats = [k @ torch.tensor(np.asarray(e))[:3] for e in img_meta["lidar2img"]["extrinsic"]]
     return torch.stack(mats)
 
@@ -98,7 +134,11 @@ def project_voxels(points: Tensor, projection: Tensor) -> Tuple[Tensor, Tensor, 
     n_v = projection.shape[0]
     p = points.reshape(1, 3, -1).expand(n_v, 3, -1)
     p = torch.cat((p, torch.ones_like(p[:, :1])), dim=1)
-    uvw = torch.bmm(projection, p)
+    if PINNED_ARITHMETIC and projection.dtype == torch.float32 and not projection.requires_grad:
+        hom = torch.cat((points.reshape(3, -1), torch.ones_like(points.reshape(3, -1)[:1])), dim=0)
+        uvw = torch.from_numpy(fma_chain_matmul(projection.numpy(), hom.numpy()[None]))
+    else:
+        uvw = torch.bmm(projection, p)
     return uvw[:, 0] / uvw[:, 2], uvw[:, 1] / uvw[:, 2], uvw[:, 2]
 
 

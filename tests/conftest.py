@@ -22,7 +22,7 @@ def load_golden(name):
     out = {}
     for k in z.files:
         a = z[k]
-        out[k] = torch.from_numpy(a) if a.ndim > 0 else a
+        out[k] = torch.from_numpy(a) if a.ndim > 0 and a.dtype.kind in "fiub" else a
     return out
 
 

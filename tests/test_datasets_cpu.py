@@ -124,3 +124,39 @@ def test_sample_format_shift_origin_and_results_roundtrip(tmp_path):
     assert len(back) == 2 and torch.equal(back[0]["boxes_3d"].tensor, results[0]["boxes_3d"].tensor) and torch.equal(back[1]["labels_3d"], results[1]["labels_3d"])
     ret = test.evaluate(back)
     assert abs(ret["mAP_0.25"] - 1.0) < 1e-6 and abs(ret["mAP_0.50"] - 1.0) < 1e-6
+
+
+def test_imresize_linear_has_cv2_geometry_and_no_antialiasing():
+    """mmcv.imresize / imrescale = cv2.resize(INTER_LINEAR) (multi_view.py:104, mmdet Resize): half-pixel centres, two taps per axis
+    however large the reduction.  Closed-form cases (cv2 itself is absent from the image)."""
+    import numpy as np
+    from nerfdet_amd.datasets import imresize_linear
+    # 4x reduction of a float ramp: dst pixel d samples the ramp at 4d + 1.5 exactly (two taps around it) -- an antialiased
+    # filter would return the same on a ramp, so the discriminating case follows
+    ramp = np.tile(np.arange(32, dtype=np.float64), (8, 1))
+    out = imresize_linear(ramp, (8, 2))
+    assert out.shape == (2, 8) and out.dtype == np.float64
+    assert np.allclose(out[0], 4 * np.arange(8) + 1.5, atol=1e-6)
+    # a single hot pixel at column 5 of 16 -> 4 columns: dst 1 samples at 5.5 = 0.5*src[5] + 0.5*src[6]; no other dst pixel sees it.
+    # Pillow's antialiased BILINEAR spreads it over dst 0..2 with weight < 0.5.
+    img = np.zeros((4, 16), dtype=np.float32)
+    img[:, 5] = 1.0
+    out = imresize_linear(img, (4, 1))
+    assert np.allclose(out[0], [0.0, 0.5, 0.0, 0.0])
+    # zero (invalid) depths do not bleed further than one destination pixel
+    depth = np.full((8, 16), 2.0)
+    depth[:, 9] = 0.0
+    out = imresize_linear(depth, (4, 2))
+    assert np.allclose(out[0], [2.0, 2.0, 1.0, 2.0])       # dst 2 samples at 9.5 -> 0.5 * 0 + 0.5 * 2
+    # uint8: fixed-point weights; upscaling 2x a two-pixel row: taps at -0.25 (clamped), 0.25, 0.75, 1.25 (clamped)
+    row = np.array([[0, 200]], dtype=np.uint8)
+    out = imresize_linear(row, (4, 1))
+    assert out.dtype == np.uint8 and out.tolist() == [[0, 50, 150, 200]]
+    # three channels, keep-ratio rescale as the nerfdet configs ask (968x1296 -> 239x320): shapes and value range
+    rs = np.random.RandomState(0)
+    frame = rs.randint(0, 256, (97, 130, 3), dtype=np.uint8)
+    out = imresize_linear(frame, (32, 24))
+    assert out.shape == (24, 32, 3) and out.dtype == np.uint8
+    exact = imresize_linear(frame.astype(np.float64), (32, 24))
+    assert np.abs(out.astype(np.float64) - exact).max() <= 1.0          # fixed point vs exact: one grey level at most
+    assert imresize_linear(frame, (130, 97)) is not frame and np.array_equal(imresize_linear(frame, (130, 97)), frame)

@@ -443,3 +443,64 @@ def test_async_tail_falls_back_like_the_synchronous_one_when_the_device_side_tai
     assert len(want["scores_3d"]) > 1024
     assert torch.equal(got["labels_3d"], want["labels_3d"]) and torch.equal(got["scores_3d"], want["scores_3d"])
     assert torch.equal(got["boxes_3d"].tensor, want["boxes_3d"].tensor)
+
+
+def test_async_handles_on_one_stream_keep_their_own_detections(device):
+    """Three different scenes queued back to back on ONE stream, collected afterwards in reverse order: every handle owns its pinned
+    landing buffer, so a later scene cannot overwrite an uncollected earlier one; a handle may be collected twice."""
+    det = _small_detector(device)
+    scenes = [_scene(device, s) for s in (1, 2, 3)]
+    with torch.no_grad():
+        want = [det.forward_test(img, [meta], denorm_images=dn, **rays)[0] for img, dn, meta, rays in scenes]
+        assert not torch.equal(want[0]["scores_3d"], want[1]["scores_3d"]) and len(want[0]["scores_3d"]) > 5
+        s = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            handles = [det.forward_test_async(img, [meta], denorm_images=dn, **rays) for img, dn, meta, rays in scenes]
+        got = {i: handles[i]()[0] for i in (2, 0, 1)}
+        again = handles[0]()[0]
+    for i in range(3):
+        assert torch.equal(got[i]["labels_3d"], want[i]["labels_3d"]) and torch.equal(got[i]["scores_3d"], want[i]["scores_3d"]), i
+        assert torch.equal(got[i]["boxes_3d"].tensor, want[i]["boxes_3d"].tensor)
+    assert torch.equal(again["scores_3d"], want[0]["scores_3d"])
+
+
+def test_checkpoint_loaded_after_a_warm_forward_takes_effect_and_round_trips(device, tmp_path):
+    """tools/test.py:113-117 builds the model, then loads the checkpoint; a server may do so after it has served scenes.  Every cached
+    weight pack (conv3d.packed / bn_affine / packed_linear / the stem and bottleneck-chain packs / the head's fused pack) must notice
+    the in-place overwrite: detections after ``load_checkpoint`` equal those of a detector BUILT with the new weights, bit for bit, and
+    save -> load reproduces them."""
+    from nerfdet_amd.checkpoint import load_checkpoint, save_checkpoint
+    img, dn, meta, rays = _scene(device, 4)
+
+    def run(d):
+        with torch.no_grad():
+            return d(img, [dict(meta)], return_loss=False, denorm_images=dn, **rays)[0]
+    det_a, det_b = _small_detector(device, seed=0), _small_detector(device, seed=1)
+    path_b = str(tmp_path / "b.pth")
+    save_checkpoint(det_b, path_b, meta=dict(CLASSES=("x",)))
+    res_b = run(det_b)
+    res_a = run(det_a)                          # warm: every pack of det_a is cached now
+    run(det_a)
+    assert len(res_a["scores_3d"]) > 5 and len(res_b["scores_3d"]) > 5
+    assert not (len(res_a["scores_3d"]) == len(res_b["scores_3d"]) and torch.equal(res_a["scores_3d"], res_b["scores_3d"]))
+    ck = load_checkpoint(det_a, path_b, map_location="cpu", strict=True)
+    assert ck["meta"]["CLASSES"] == ("x",)
+    res_ab = run(det_a)
+    for k in ("labels_3d", "scores_3d"):
+        assert torch.equal(res_ab[k], res_b[k]), f"{k}: stale weight pack after load_checkpoint"
+    assert torch.equal(res_ab["boxes_3d"].tensor, res_b["boxes_3d"].tensor)
+    # the same through the hipGraph replay path's static copies and the two-in-flight path
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.no_grad(), torch.cuda.stream(s):
+        fin = det_a.forward_test_async(img, [dict(meta)], denorm_images=dn, **rays)
+    assert torch.equal(fin()[0]["scores_3d"], res_b["scores_3d"])
+    # save -> load into a third detector reproduces the detections bit for bit
+    path_a = str(tmp_path / "a.pth")
+    save_checkpoint(det_a, path_a)
+    det_c = _small_detector(device, seed=2)
+    run(det_c)
+    load_checkpoint(det_c, path_a, map_location="cpu", strict=True)
+    res_c = run(det_c)
+    assert torch.equal(res_c["scores_3d"], res_b["scores_3d"]) and torch.equal(res_c["boxes_3d"].tensor, res_b["boxes_3d"].tensor)

@@ -60,9 +60,8 @@ def _detections_agree(res, ref, what):
 
 def _near_boundary(meta, n_voxels, voxel_size, hw, tol=1e-4):
     """Voxels with a view whose stride-4 or stride-1 pixel coordinate lies within ``tol`` of a .5 rounding boundary: the only
-    places where a 1-ulp difference of the projection (another BLAS kernel on another host CPU) may pick the neighbouring pixel
-    ("index parity at rounding boundaries").  They are excluded from the value comparison, must be rare,
-    and every disagreement must lie among them."""
+    places where a 1-ulp difference of the projection could pick the neighbouring pixel ("index parity at
+    rounding boundaries").  Reported, no longer excluded: they must agree like every other voxel."""
     from test_volume_gpu import near_boundary_voxels
     pts = O.get_points(n_voxels, voxel_size, meta["lidar2img"]["origin"])
     h, w = hw
@@ -100,18 +99,18 @@ def test_forward_test_at_baseline_size_vs_oracle(device, workload):
     with torch.no_grad():
         ov = O.extract_volume(f_host, batch_cpu["denorm_images"][0], meta, w["n_voxels"], w["voxel_size"], det_cpu.mapping[0].weight,
                               det_cpu.mapping[0].bias, det_cpu.nerf_mlp.state_dict())
+    # no exclusion band: the oracle evaluates the projection in the build container's operation order on any host (oracle.PINNED_ARITHMETIC,
+    # pinned to the real reference at this size by tests/golden/fullsize_cfg*.npz), so rounding-boundary voxels must agree too
     excl = _near_boundary(meta, w["n_voxels"], w["voxel_size"], w["img_hw"])
-    assert float(excl.float().mean()) < 0.02
     cnt_bad = (out["valid"].cpu() != ov["valid"]).reshape(-1)
-    assert not (cnt_bad & ~excl).any(), "view counts differ from the oracle away from rounding boundaries"
+    assert not cnt_bad.any(), f"view counts differ from the oracle in {int(cnt_bad.sum())} voxels ({int((cnt_bad & excl).sum())} of them near a rounding boundary)"
     assert float((ov["valid"] > 0).float().mean()) > 0.2
     scale = max(1.0, float(ov["volume"].abs().max()))
     verr = (out["volume"].cpu() - ov["volume"]).abs().reshape(256, -1).max(0)[0]
-    err = float(verr[~excl].max())
+    err = float(verr.max())
     assert err <= 1e-4 * scale, f"gated voxel features differ from the oracle by {err} (scale {scale})"
     n_flip = int((verr > 1e-4 * scale).sum())
-    assert n_flip <= 0.001 * verr.numel(), f"{n_flip} voxels picked a neighbouring pixel"
-    seen = (ov["valid"].reshape(-1) > 0) & ~excl     # unseen voxels: the reference's n_v*b/1e-8 "mean", zeroed by the gating
+    seen = ov["valid"].reshape(-1) > 0     # unseen voxels: the reference's n_v*b/1e-8 "mean", zeroed by the gating
     gerr = float((out["global_feat"].cpu() - ov["global_feat"])[seen].abs().max())
     assert gerr <= 1e-4 * max(1.0, float(ov["global_feat"][seen].abs().max())), gerr
 
@@ -144,7 +143,7 @@ def test_forward_test_at_baseline_size_vs_oracle(device, workload):
         assert float((f_host - feats_cpu).abs().max()) <= 1e-4 * fs, "FPN level 0 differs from PyTorch-CPU"
         ov2 = O.extract_volume(feats_cpu, batch_cpu["denorm_images"][0], meta, w["n_voxels"], w["voxel_size"], det_cpu.mapping[0].weight,
                                det_cpu.mapping[0].bias, det_cpu.nerf_mlp.state_dict())
-        assert float((out["volume"].cpu() - ov2["volume"]).abs().reshape(256, -1).max(0)[0][~excl].max()) <= 1e-4 * scale
+        assert float((out["volume"].cpu() - ov2["volume"]).abs().max()) <= 1e-4 * scale
         n3b = O.neck3d_forward(dict(det_cpu.neck_3d.state_dict()), ov2["volume"].unsqueeze(0))
         ref = O.head_get_bboxes(*O.head_forward(det_cpu.bbox_head.state_dict(), n3b), ov2["valid"].unsqueeze(0).float(), meta["lidar2img"]["origin"], w["voxel_size"],
                                 tc.nms_pre, tc.score_thr, tc.iou_thr)
@@ -185,16 +184,14 @@ def test_cfg5_res101_101_views_320x480_80x80x32(device):
         glob = O.density_features(vol, rgb_vol, cnt, det_cpu.mapping[0].weight, det_cpu.mapping[0].bias)
         dens = O.nerf_query_density(det_cpu.nerf_mlp.state_dict(), sub.view(3, -1).permute(1, 0).contiguous(), glob)
         exp = O.gate_volume(mean, cnt, dens)
-    excl = _near_boundary(meta, w["n_voxels"], w["voxel_size"], w["img_hw"])[sel]
-    assert float(excl.float().mean()) < 0.03
     cnt_bad = out["valid"].reshape(-1)[sel.to(device)].cpu() != cnt.reshape(-1)
-    assert not (cnt_bad & ~excl).any(), "view counts differ from the oracle away from rounding boundaries"
+    assert not cnt_bad.any(), f"view counts differ from the oracle in {int(cnt_bad.sum())} of the sampled voxels"
     assert int(cnt.max()) > 20 and float((cnt > 0).float().mean()) > 0.2
     gv = out["volume"].reshape(256, -1)[:, sel.to(device)].cpu()
     scale = max(1.0, float(exp.abs().max()))
-    err = float((gv - exp.reshape(256, -1)).abs().max(0)[0][~excl].max())
+    err = float((gv - exp.reshape(256, -1)).abs().max())
     assert err <= 1e-4 * scale, f"gated voxel features differ from the oracle by {err}"
-    seen = (cnt.reshape(-1) > 0) & ~excl
+    seen = cnt.reshape(-1) > 0
     gerr = float((out["global_feat"][sel.to(device)].cpu() - glob)[seen].abs().max())
     assert gerr <= 1e-4 * max(1.0, float(glob[seen].abs().max())), gerr
     # dense part on the GPU's own volume

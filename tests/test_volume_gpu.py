@@ -168,10 +168,8 @@ def test_cfg2_full_size_vs_oracle_and_properties(device):
     frac = valid.float().mean().item()
     assert 0.2 < frac < 0.45, frac
     bad = (gcnt.cpu() != cnt).reshape(-1)
-    assert not (bad & ~excl).any(), "view count differs away from rounding boundaries"
-    assert excl.float().mean() < 0.01
-    ok = ~(bad | excl)
-    diff = (got.cpu() - mean).reshape(c, -1)[:, ok].abs().max().item()
+    assert not bad.any(), f"view count differs from the (host-independent) oracle in {int(bad.sum())} voxels"     # no exclusion band
+    diff = (got.cpu() - mean).abs().max().item()
     assert diff <= ATOL, diff
     print(f"cfg2: valid fraction {frac:.3f}, boundary voxels {int(excl.sum())}, count mismatches {int(bad.sum())}, max|d|={diff:.2e}")
     # size-independent properties at full size
@@ -249,12 +247,9 @@ def test_cfg5_scale_sampled_voxels_and_properties(device):
     vol, valid = O.backproject(feats, sub, proj)
     mean, ocnt, _ = O.aggregate_views(vol, valid)
     exp = O.gate_volume(mean, ocnt, -torch.log1p(-alpha[sel]).view(-1, 1))  # density with 1-exp(-d) == alpha
-    excl = near_boundary_voxels(sub, proj, hw[1] // 4, hw[0] // 4).reshape(-1)
     gcnt = cnt.reshape(-1)[sel.to(device)].cpu()
-    bad = gcnt != ocnt.reshape(-1)
-    assert not (bad & ~excl).any()
-    ok = ~(bad | excl)
-    d = (got.reshape(c, -1)[:, sel.to(device)].cpu() - exp.reshape(c, -1))[:, ok].abs().max().item()
+    assert torch.equal(gcnt, ocnt.reshape(-1)), "view counts differ from the (host-independent) oracle"      # no exclusion band
+    d = (got.reshape(c, -1)[:, sel.to(device)].cpu() - exp.reshape(c, -1)).abs().max().item()
     assert d <= ATOL, d
     # properties on the full grid
     assert (got[:, cnt[0] == 0] == 0).all()

@@ -9,8 +9,6 @@ event-timed forward launches of the packed ray sampler K4 (algorithmic bytes per
 import argparse
 import json
 import os
-import socket
-import subprocess
 import sys
 import time
 
@@ -22,18 +20,8 @@ sys.path.insert(0, ROOT)
 
 
 def launch(args):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = rc or p.wait()
-    return rc
+    from nerfdet_amd.dist import launch_local_ranks      # the first failing rank terminates the others instead of leaving them in a collective
+    return launch_local_ranks(__file__, sys.argv[1:], args.gpus)
 
 
 def main():
