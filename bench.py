@@ -285,10 +285,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+    from nerfdet_amd import dist as D
+    if world > 1 or D.launched():      # under a launcher also a single rank joins a process group: the 1-GPU run exercises the RCCL path
+        D.init_dist("nccl")
         torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // world)))   # N ranks share the host: do not oversubscribe it while building
+    grouped = torch.distributed.is_available() and torch.distributed.is_initialized()
 
     import nerfdet_amd.conv3d as C3
     from nerfdet_amd import trace
@@ -318,7 +319,7 @@ def main():
                 return det_gpu(return_loss=False, **batch)
 
     def barrier():
-        if world > 1:
+        if grouped:
             torch.distributed.barrier()
 
     for _ in range(args.warmup):
@@ -456,6 +457,7 @@ def main():
                                             k1_algorithmic_bytes(w)),
             "roofline_density_features": hbm_line("k_density_features", "k_density_features (K2: mapped features + RGB -> per-voxel mean / exp(-var) rows)",
                                                   k2_algorithmic_bytes(w)),
+            "collectives": (f"{torch.distributed.get_backend()} (timing barrier + max-over-ranks only)" if grouped else "none (bare single process)"),
             "execution": "hipGraph replay (2 graphs) + eager K1 + eager post-processing" if args.graph else "eager launches",
             "stages_ms": stages,
             "detections_last_step": int(len(res[0]["scores_3d"])),
@@ -468,7 +470,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, build_model(w), batch_cpu)
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         torch.distributed.destroy_process_group()
 
 

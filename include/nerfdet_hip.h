@@ -48,7 +48,7 @@ int ndet_get_points(float* points, int nx, int ny, int nz, const float* voxel_si
  * want one pixel's channels contiguous (SURVEY.md section 7 "Layout").  No reference counterpart. */
 int ndet_nchw_to_nhwc(const float* src, float* dst, int n, int c, int hw, void* stream);
 
-/* Measurement aid: dst[i] = src[i] with 16-byte accesses, grid-stride over 8 192 workgroups.  Its rate (2 * 4 * n_floats / time) is the
+/* Measurement aid: dst[i] = src[i], one non-temporal 16-byte access per thread.  Its rate (2 * 4 * n_floats / time) is the
  * empirical HBM ceiling bench.py prices the gather kernels against, next to the 8 TB/s specification (SURVEY.md 8d "the builder must
  * also report an empirical copy-kernel ceiling"; the reference's harness has no counterpart, tools/benchmark.py:63-89 times the model only).
  * Pointers 16-byte aligned, n_floats % 4 == 0. */

@@ -108,8 +108,13 @@ class RayViewStats(torch.autograd.Function):
         assert (f.stride(0), f.stride(2)) == (df.stride(0), df.stride(1)), "saved input and gradient buffer must share their pitches"
         from . import rays
         fn = _lib.load().ndet_ray_view_stats_packed_bwd if rays.packed_ok(n_v, d, backward=True) else _lib.load().ndet_ray_view_stats_bwd
-        check(fn(_ptr(g), _ptr(pts), pts.shape[0], _ptr(ke), n_v, ctx.hw[0], ctx.hw[1], _ptr(f), d, hf, wf, f.stride(0), f.stride(2), _ptr(df),
-                 _stream(g)), "ray_view_stats_bwd")
+        from . import trace
+        # one float atomic per (sample, view, bilinear tap, channel) whose view sees the sample: the upper bound n * n_v * 4 * d is what the
+        # kernel would issue with every view valid (the ring scenes of bench/tests: ~30 % are)
+        trace.span("k_ray_stats_packed_bwd" if rays.packed_ok(n_v, d, backward=True) else "k_ray_view_stats_bwd",
+                   lambda: check(fn(_ptr(g), _ptr(pts), pts.shape[0], _ptr(ke), n_v, ctx.hw[0], ctx.hw[1], _ptr(f), d, hf, wf, f.stride(0), f.stride(2),
+                                    _ptr(df), _stream(g)), "ray_view_stats_bwd"),
+                   bytes=4 * (g.numel() + n_v * d * hf * wf), atomics_max=pts.shape[0] * n_v * 4 * d, kind="atomics")
         return df.permute(0, 3, 1, 2), None, None, None
 
 

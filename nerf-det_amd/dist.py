@@ -15,15 +15,22 @@ import torch
 import torch.distributed as dist
 
 
+def launched() -> bool:
+    """True under a launcher (``torch.distributed.run``, :func:`launch_local_ranks`): the env:// rendezvous variables are set."""
+    return all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))
+
+
 def init_dist(backend: str = "nccl") -> tuple:
-    """tools/train.py:98-102 ``init_dist('pytorch')``: env:// rendezvous, device = LOCAL_RANK."""
+    """tools/train.py:98-102 ``init_dist('pytorch')``: env:// rendezvous, device = LOCAL_RANK.  Under a launcher the process group
+    is created whatever the world size -- also for a single rank, so that the RCCL code path of a 1-GPU run is the 8-GPU one."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if backend == "nccl":
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
-        dist.init_process_group(backend)
+    if (world > 1 or launched()) and not dist.is_initialized():
+        kw = dict(device_id=torch.device("cuda", local)) if backend == "nccl" else {}
+        dist.init_process_group(backend, **kw)
     return rank, world, local
 
 
@@ -72,8 +79,7 @@ def multi_gpu_test(model: Callable, scenes: Sequence, to_device: Callable = lamb
 
 def max_over_ranks(seconds: float, device=None) -> float:
     """bench.py timing: the step time of the job is the slowest rank's."""
-    rank, world = get_dist_info()
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

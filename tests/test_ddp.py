@@ -152,6 +152,7 @@ def _run(dev_type, tol):
             ref = _single_rank_reference(torch.device("cpu"), world, holder)
     else:
         ref = _single_rank_reference(torch.device("cuda", 0), world, None)
+    worst = 0.0
     for k in WATCH:
         mean = (ref[0][0][k] + ref[1][0][k]) / 2
         assert float(mean.abs().max()) > 0, k
@@ -159,6 +160,7 @@ def _run(dev_type, tol):
             g = got[r][0][k]
             assert g is not None, k
             err = float((g - mean).abs().max()) / max(float(mean.abs().max()), 1e-12)
+            worst = max(worst, err)
             assert err <= tol, f"{k}: rank {r} gradient differs from the mean of the single-rank gradients by {err:.2e}"
     for k in DEAD:                                   # never touched by forward: no gradient, and no reducer hang either
         assert all(got[r][0][k] is None or float(got[r][0][k].abs().max()) == 0 for r in range(world)), k
@@ -168,6 +170,7 @@ def _run(dev_type, tol):
         assert abs(got[0][1][key] - want) <= 1e-3 * max(1.0, abs(want)) and got[0][1][key] == got[1][1][key], key
     assert abs(got[0][2] - got[1][2]) <= 1e-4 * got[0][2]      # same clipped-gradient norm on both ranks
     assert torch.equal(got[0][3], got[1][3]) or float((got[0][3] - got[1][3]).abs().max()) < 1e-7   # replicas stay in step
+    print(f"DDP 2 ranks ({dev_type}): worst gradient difference {worst:.2e} of the gradient scale (tolerance {tol:.0e})")
 
 
 @pytest.mark.timeout(900)
@@ -178,4 +181,48 @@ def test_ddp_two_ranks_gloo_cpu_gradients_are_the_rank_mean():
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
 def test_ddp_two_ranks_hip_autograd_functions_gradients_are_the_rank_mean(device):
-    _run("cuda", 1e-2)   # float atomics in the scatter kernels + library backward kernels: run-to-run noise of a few 1e-3 of the scale
+    # two repeated single-process steps differ by <= 1.1e-6 of the gradient scale (float atomics; measured by tests/rccl_single_rank.py on
+    # MI355X, round 3); the rank mean adds one fp32 rounding per element
+    _run("cuda", 5e-5)
+
+
+def _child_env(port):
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    return env
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_rccl_single_rank_bringup(device):
+    """RCCL itself, on the one GPU there is: a fresh child process joins an "nccl" process group of world size 1 and runs DDP's bucketed
+    gradient all-reduce, the head's reduce_mean and the loss logging over it (tests/rccl_single_rank.py).  Gradients through DDP/RCCL
+    must equal the plain step's within 3x the measured run-to-run noise of the atomics (floor 2e-4 of the gradient scale)."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_single_rank.py")], env=_child_env(_free_port()), capture_output=True, text=True,
+                         timeout=800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rep["ok"] and rep["backend"] == "nccl" and rep["dead_ok"] and rep["finite"]
+    assert abs(rep["loss_plain"] - rep["loss_ddp"]) <= 1e-4 * max(1.0, abs(rep["loss_plain"]))
+    for k in WATCH:
+        assert rep["err"][k] <= max(3 * rep["noise"][k], 2e-4), f"{k}: DDP-over-RCCL gradient differs by {rep['err'][k]:.2e} (noise {rep['noise'][k]:.2e})"
+    print("RCCL single-rank bring-up:", {k: (f"{rep['err'][k]:.1e}", f"{rep['noise'][k]:.1e}") for k in WATCH}, "rccl", rep["rccl"])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_under_torch_distributed_run_uses_rccl(device):
+    """The driver's multi-GPU launch line with one rank: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 1 ...`` -- bench.py joins the nccl group, its barrier and max-over-ranks run on RCCL."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline",
+           "--no-serving"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["collectives"].startswith("nccl") and line["value"] > 0 and line["median_ms"] > 0

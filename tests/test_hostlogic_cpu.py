@@ -104,3 +104,48 @@ def test_training_and_fusion_eligibility_rules():
         conv3d.set_arithmetic(prev)
     assert conv3d.choose_tiling_split(240000, 256, 2, 100064, 0) == (100064, 1)   # direct-epilogue tiles never split K
     assert conv3d.choose_tiling_split(2304, 256, 375)[1] > 4 and conv3d.choose_tiling_split(2304, 256, 375)[0] == 128256   # ... the 128 x 256 tile (code 128256) does
+
+
+def test_ssim_closed_form_cases():
+    """scikit-image is absent, so ``structural_similarity`` cannot pin rays.compute_ssim (save_rendered_img.py:21-36); it is held to the cases
+    whose SSIM follows from the definition in closed form (data range 2, K1 = 0.01, K2 = 0.03 -> C1 = 4e-4, C2 = 3.6e-3), for both the
+    product's torch form and the oracle's scipy form."""
+    import numpy as np
+    import torch
+    from nerfdet_amd import rays
+    from oracle import render_eval_oracle as R
+    c1, c2 = (0.01 * 2.0) ** 2, (0.03 * 2.0) ** 2
+    rs = np.random.RandomState(0)
+    x = rs.rand(19, 23, 3)
+
+    def both(a, b):
+        got = float(rays.compute_ssim(torch.from_numpy(a), torch.from_numpy(b)))
+        assert abs(got - R.ssim(a, b)) < 1e-12
+        return got
+    # identical images: every window has SSIM exactly 1
+    assert abs(both(x, x) - 1.0) < 1e-14
+    # two constant images a and a + d: variances and covariance vanish -> (2 a (a+d) + C1) / (a^2 + (a+d)^2 + C1)
+    a, d = 0.3, 0.25
+    want = (2 * a * (a + d) + c1) / (a * a + (a + d) ** 2 + c1)
+    assert abs(both(np.full((9, 11, 3), a), np.full((9, 11, 3), a + d)) - want) < 1e-12
+    # a constant offset of a textured image leaves the contrast / structure term at exactly 1: SSIM = mean over windows of the luminance term
+    y = x + 0.1
+    lum = []
+    for c in range(3):
+        for i in range(19 - 6):
+            for j in range(23 - 6):
+                m = x[i:i + 7, j:j + 7, c].mean()
+                lum.append((2 * m * (m + 0.1) + c1) / (m * m + (m + 0.1) ** 2 + c1))
+    assert abs(both(x, y) - float(np.mean(lum))) < 1e-10
+    # a +-0.5 stripe image against its negative: covariance = -variance, means of opposite sign:
+    # SSIM window = (-2 m^2 + C1)(-2 v + C2) / ((2 m^2 + C1)(2 v + C2))
+    s = np.where((np.arange(23) % 2) == 0, 0.5, -0.5)[None, :, None] * np.ones((19, 1, 3))
+    vals = []
+    for j in range(23 - 6):
+        w = np.tile(s[0, j:j + 7, 0], (7, 1))
+        m, v = w.mean(), w.var(ddof=1)
+        vals.append(((-2 * m * m + c1) * (-2 * v + c2)) / ((2 * m * m + c1) * (2 * v + c2)))
+    assert abs(both(s, -s) - float(np.mean(vals))) < 1e-10 and both(s, -s) < 1.0
+    # symmetric, and bounded by 1
+    z = rs.rand(19, 23, 3)
+    assert abs(both(x, z) - both(z, x)) < 1e-14 and both(x, z) < 1.0

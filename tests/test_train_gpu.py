@@ -1,0 +1,72 @@
+"""Training-path insurance on the GPU (nerfdet.py:271-321, imvoxel_head_v2.py:116-203): a fixed scene is fitted for 30 optimizer steps and
+every one of the five losses must fall; bf16 and fp32-class gradients of one cfg3-shaped step must point the same way, parameter group
+by parameter group.  (After MIOpen's channels-last-3d backward turned out 43 % wrong -- DESIGN.md 9.2 -- aggregate checks like these are
+cheap insurance on top of the per-kernel gradient tests of tests/test_backward_gpu.py and tests/test_conv_train_gpu.py.)"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LOSSES = ("loss_centerness", "loss_bbox", "loss_cls", "loss_nvs", "loss_depth")
+GROUPS = ("backbone.layer2", "backbone.layer3", "backbone.layer4", "neck.lateral_convs", "neck.fpn_convs.0", "mapping", "nerf_mlp",
+          "neck_3d.down_layer_0", "neck_3d.down_layer_1", "neck_3d.down_layer_2", "neck_3d.up_block", "neck_3d.out_block", "bbox_head")
+
+
+@pytest.mark.timeout(900)
+def test_thirty_steps_on_a_fixed_scene_lower_all_five_losses(device):
+    from test_ddp import _build, _scene
+    import nerfdet_amd.rays as R
+    from nerfdet_amd.train import build_optimizer, train_one_step
+    det = _build(device)
+    opt = build_optimizer(det)                       # config:167-172: AdamW 2e-4, backbone x0.1
+    scene = _scene(0, device)
+    R.rng = np.random.RandomState(234)
+    torch.manual_seed(3)
+    hist = [train_one_step(det, scene, opt)["log_vars"] for _ in range(30)]
+    assert all(np.isfinite(h["loss"]) for h in hist)
+    first = {k: float(np.mean([h[k] for h in hist[:3]])) for k in LOSSES + ("loss",)}
+    last = {k: float(np.mean([h[k] for h in hist[-3:]])) for k in LOSSES + ("loss",)}
+    print("fixed scene, steps 1-3 -> 28-30:", {k: (round(first[k], 4), round(last[k], 4)) for k in first})
+    for k in LOSSES + ("loss",):
+        assert last[k] < first[k], f"{k} did not fall: {first[k]:.4f} -> {last[k]:.4f}"
+    assert last["loss"] < 0.9 * first["loss"]
+
+
+@pytest.mark.timeout(900)
+def test_bf16_gradients_point_along_the_fp32_class_gradients_at_cfg3_shapes(device):
+    """BASELINE configs[2] trains in bf16: one step at its per-rank shapes (40 source + 10 target views 240x320, 40x40x16 voxels, 2 048 rays x 64
+    samples) in both arithmetics, same rays and sampling noise; per parameter group the cosine between the two gradients is >= 0.999
+    and their norms agree within 2 %."""
+    from nerfdet_amd import conv3d, rays
+    from nerfdet_amd.presets import build_nerfdet
+    from nerfdet_amd.synth import batch_to, train_scene
+    torch.manual_seed(0)
+    det = build_nerfdet(50, depth_supervise=True)
+    with torch.no_grad():
+        det.neck.fpn_convs[0].conv.weight.mul_(1 / 30.0)
+        det.nerf_mlp.mlp.sigma_layer.output_layer.bias.fill_(1.0)
+    det.to(device).train()
+    scene = batch_to(train_scene(40, (240, 320), t_views=10, n_boxes=8, seed=4), device)
+    grads = {}
+    for mode in ("bf16x3", "bf16"):
+        prev = conv3d.set_arithmetic(mode)
+        try:
+            rays.rng = np.random.RandomState(234)
+            torch.manual_seed(5)
+            det.zero_grad(set_to_none=True)
+            det.train_step(scene)["loss"].backward()
+            named = dict(det.named_parameters())
+            grads[mode] = {g: torch.cat([p.grad.detach().float().reshape(-1) for n, p in named.items() if n.startswith(g) and p.grad is not None])
+                           for g in GROUPS}
+        finally:
+            conv3d.set_arithmetic(prev)
+    report = {}
+    for g in GROUPS:
+        a, b = grads["bf16x3"][g].double(), grads["bf16"][g].double()
+        assert a.numel() > 0 and float(a.norm()) > 0, g
+        report[g] = (float(torch.dot(a, b) / (a.norm() * b.norm())), float(b.norm() / a.norm()))
+    print("bf16 vs fp32-class gradients (cosine, norm ratio):", {g: (round(c, 5), round(r, 4)) for g, (c, r) in report.items()})
+    for g, (c, r) in report.items():
+        assert c >= 0.999, f"{g}: cosine {c:.5f}"
+        assert abs(r - 1) <= 0.02, f"{g}: norm ratio {r:.4f}"

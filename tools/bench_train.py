@@ -50,39 +50,81 @@ def main():
         det.neck.fpn_convs[0].conv.weight.mul_(1 / 30.0)
         det.nerf_mlp.mlp.sigma_layer.output_layer.bias.fill_(1.0)
     det.to(dev).train()
-    model = wrap_ddp(det, dev) if world > 1 else det
+    grouped = torch.distributed.is_available() and torch.distributed.is_initialized()      # also a single rank under a launcher
+    model = wrap_ddp(det, dev) if grouped else det
     data = batch_to(train_scene(args.views, (240, 320), t_views=10, n_boxes=8, seed=rank), dev)
     opt = build_optimizer(model)
-    rec = trace.Recorder()
+    state = {"step": 0}
+    # ~450 convolution launches per step (forward, data and weight gradients): their event pairs are sampled on every 4th timed step
+    rec = trace.Recorder(sample=lambda name: (not name.startswith(("k_conv", "f32:", "bf16x3:", "bf16:"))) or state["step"] % 4 == 0)
     for _ in range(args.warmup):
         out = train_one_step(model, data, opt)
     trace.recorder = rec
-    if world > 1:
+    if grouped:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = train_one_step(model, data, opt)
+    ticks = [t0]
+    for i in range(args.steps):
+        state["step"] = i
+        out = train_one_step(model, data, opt)          # ends with the step's one host sync (the logged scalars)
+        ticks.append(time.perf_counter())
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         torch.distributed.barrier()
     dt = D.max_over_ranks((time.perf_counter() - t0) / args.steps, dev)
     trace.recorder = None
     if rank == 0:
+        per_step = sorted((b - a) * 1e3 for a, b in zip(ticks, ticks[1:]))
+        pct = lambda q: per_step[min(len(per_step) - 1, int(round(q * (len(per_step) - 1))))]
+        n_conv_steps = len([i for i in range(args.steps) if i % 4 == 0])
         spans = rec.span_ms()
+        arith = C3.ARITHMETIC
+        conv_peak = {"bf16x3": 2500.0 / 6.0, "bf16": 2500.0, "f32": 157.3}[arith]
+        peak_note = {"bf16x3": "dense bf16 MFMA peak 2500 TFLOP/s / 6 issued products per algorithmic multiply-add", "bf16": "dense bf16 MFMA peak",
+                     "f32": "dense fp32-input MFMA peak"}[arith]
+        conv = {k: v for k, v in spans.items() if v and v[0][1].get("kind") == "conv"}
+        by_kernel = {k: [sum(i["flops"] for _, i in v), sum(ms for ms, _ in v), len(v)] for k, v in conv.items()}
+        line = dict(metric="training steps/sec (cfg3 shapes)", value=world / dt, unit="scenes/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                    ms_per_step=dt * 1e3, median_ms=pct(0.5), p10_ms=pct(0.1), p90_ms=pct(0.9), higher_is_better=True, scaling="weak", dtype=arith,
+                    data="synthetic",
+                    config=dict(workload=f"cfg3 shapes, {world} GPU(s) x 1 scene/step, {arith} convolutions: {args.views} source views 240x320 + 10 NeRF target "
+                                         f"views, 40x40x16 voxels, 2048 rays x 64 samples, {'5' if args.depth_supervise else '4'} losses + backward + clip + AdamW"
+                                         + (", DDP over RCCL" if grouped else ""), scenes_per_step=world),
+                    log_vars=out["log_vars"], grad_norm=out.get("grad_norm"), peak_mem_GB=torch.cuda.max_memory_allocated() / 1e9)
+        if by_kernel:
+            dom, (df, dms, dn) = max(by_kernel.items(), key=lambda kv: kv[1][1])
+            tf = df / (dms * 1e-3) / 1e12
+            line["roofline"] = dict(kernel=f"{dom} (the convolution instantiation with the largest share of the training step: forward, data-gradient and "
+                                           f"weight-gradient launches all run on it)", bound="mfma", achieved=tf, peak=conv_peak, unit="TFLOP/s", frac=tf / conv_peak,
+                                    traffic=None, peak_note=peak_note, launches_per_step=dn / n_conv_steps, avg_launch_ms=dms / dn,
+                                    total_ms_per_step=dms / n_conv_steps, sampled_steps=n_conv_steps)
+            cf, cms, cn = (sum(v[i] for v in by_kernel.values()) for i in range(3))
+            line["roofline_all_convolutions"] = dict(bound="mfma", achieved=cf / (cms * 1e-3) / 1e12, peak=conv_peak, unit="TFLOP/s",
+                                                     frac=cf / (cms * 1e-3) / 1e12 / conv_peak, launches_per_step=cn / n_conv_steps,
+                                                     total_ms_per_step=cms / n_conv_steps, algorithmic_flops_per_step=cf / n_conv_steps,
+                                                     per_kernel={k: dict(launches_per_step=v[2] / n_conv_steps, avg_launch_ms=v[1] / v[2],
+                                                                         tflops=v[0] / (v[1] * 1e-3) / 1e12) for k, v in sorted(by_kernel.items())})
         k4 = spans.get("k_ray_stats_packed") or spans.get("k_ray_view_stats") or []
-        line = dict(workload=f"cfg3 shapes, {world} GPU(s) x 1 scene/step, {C3.ARITHMETIC} convolutions: {args.views} source views 240x320, 2048 rays x 64 samples, "
-                             f"{'5' if args.depth_supervise else '4'} losses + backward + clip + AdamW" + (", DDP over RCCL" if world > 1 else ""),
-                    n_gpus=world, ms_per_train_step=dt * 1e3, scenes_per_s=world / dt, log_vars=out["log_vars"], grad_norm=out.get("grad_norm"),
-                    peak_mem_GB=torch.cuda.max_memory_allocated() / 1e9)
         if k4:
             ms = sorted(m for m, _ in k4)
             b = k4[0][1]["bytes"]
+            med = ms[len(ms) // 2]
             line["roofline_k4_forward"] = dict(kernel="k_ray_stats_packed (K4: Projector.compute + compute_mask_points fused)", bound="hbm",
-                                               algorithmic_bytes=b, median_launch_ms=ms[len(ms) // 2], achieved=b / ms[len(ms) // 2] / 1e6,
-                                               peak=8000.0, unit="GB/s", frac=b / ms[len(ms) // 2] / 1e6 / 8000.0)
+                                               algorithmic_bytes=b, median_launch_ms=med, achieved=b / med / 1e6, peak=8000.0, unit="GB/s",
+                                               frac=b / med / 1e6 / 8000.0)
+        k4b = spans.get("k_ray_stats_packed_bwd") or spans.get("k_ray_view_stats_bwd") or []
+        if k4b:
+            ms = sorted(m for m, _ in k4b)
+            med = ms[len(ms) // 2]
+            info = k4b[0][1]
+            line["roofline_k4_backward"] = dict(kernel="k_ray_stats_packed<true> (K4 backward: scatter of d(mean), d(var) into the mapped feature maps)",
+                                                bound="hbm", algorithmic_bytes=info["bytes"], median_launch_ms=med, achieved=info["bytes"] / med / 1e6,
+                                                peak=8000.0, unit="GB/s", frac=info["bytes"] / med / 1e6 / 8000.0, atomics_upper_bound=info["atomics_max"],
+                                                note="the scatter is bound by float-atomic throughput (~1.3 TB/s of 4-byte adds measured on MI355X), not by "
+                                                     "the algorithmic bytes")
         print(json.dumps(line))
-    if world > 1:
+    if grouped:
         torch.distributed.destroy_process_group()
 
 
