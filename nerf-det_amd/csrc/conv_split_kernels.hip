@@ -977,6 +977,330 @@ static int split_launch_ws(const Conv3dParams& p, hipStream_t st, const char* fn
 
 
 // ------------------------------------------------------------------------------------------------
+// Persistent form of the wave-specialised tile (BM x 256, BM = 128 or 64).  The one-shot kernel above spends a fixed 6 - 8 us per
+// workgroup outside its K walk -- row addresses, the first loads' latency, the C tile through LDS, two barriers per half -- with one
+// workgroup per CU and nothing else on the CU to use that time: 1/3 of a workgroup's life at K = 256 (8 steps), 1/5 at K = 512.
+// Here one workgroup per CU walks a list of tiles:
+//   * the CONSUMERS store their accumulators straight from the 16x16 MFMA's C layout (a register = 16 consecutive channels of 4 rows;
+//     buffer stores, lane part of the address in one VGPR, the register's row in the scalar offset, rows past M outside the descriptor);
+//     no LDS round trip and no barrier in the epilogue, so
+//   * the PRODUCERS are free the moment the last K step's barrier falls: they compute the next tile's addresses, fetch its first two
+//     K steps, split step 0 into LDS and start its weight DMA WHILE the consumers drain the current tile -- the next tile's first MFMA
+//     issues as soon as the last store has.
+// Tiles are dealt so that the workgroups of one XCD (blockIdx % 8) hold neighbouring tiles: the column tiles of one row tile (same
+// activation rows) and the row tiles of one weight slice meet in the same L2.  Split-K partials, the plain and the nearest-x2 residual,
+// both ReLU positions: as above, bit-identical results.  BM = 64 (four consumer waves side by side, 64 x 64 each) doubles the tile
+// count of launches that would otherwise fill half of the chip (M = 15 000: 118 row tiles).
+// ------------------------------------------------------------------------------------------------
+// 8-byte LDS store the compiler does not see as one.  SIInsertWaitcnts drains vmcnt before any LDS store that follows an LDS-DMA in
+// program order (it cannot tell that the DMA's destination and the store's do not overlap), which forced the one-shot tile to issue its
+// weight DMA AFTER the activation split -- the DMA's whole latency then sat between the split and the barrier, every K step.  Here the
+// DMA goes out first and the split runs under its latency.  No result register is involved (DESIGN.md 9.1's rule concerns loads); the
+// stores are retired by an explicit lgkmcnt(0) before the barrier that publishes the stage.
+template <int OFF>
+__device__ __forceinline__ void lds_store64_unseen(unsigned addr, uint2 v) {
+    const unsigned long long d = ((unsigned long long)v.y << 32) | v.x;
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(d), "n"(OFF) : "memory");
+}
+
+#ifndef WSP_DEPTH
+#define WSP_DEPTH 2    // K steps of activation loads in flight per producer wave
+#endif
+template <bool ONE, int BM, int NCONS>
+__global__ __launch_bounds__(64 * (NCONS + 4), 1) void k_conv_split_wsp(const Conv3dParams p, const uint16_t* __restrict__ wsplit, int n_mt, int n_nt) {
+    static_assert((BM == 128 && (NCONS == 4 || NCONS == 8)) || (BM == 64 && NCONS == 4), "consumer layouts: 2 x 2 of 64 x 128, 2 x 4 of 64 x 64, 1 x 4 of 64 x 64");
+    constexpr int CW = NCONS / (BM / 64);                 // consumer waves along N (BM / 64 along M)
+    constexpr int WNC = WS_BN / CW, NTB = WNC / 16;       // columns and 16-column MFMA tiles per consumer wave
+    constexpr int APL = BM * CBK, BPL = WS_BN * CBK;      // one plane, in bf16 elements
+    constexpr int NPL = ONE ? 1 : 3;
+    constexpr int STAGE = NPL * (APL + BPL);
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < NCONS;
+    const int wm = (wave % NCONS) / CW, wn = (wave % NCONS) % CW;
+
+    const int cin_steps = p.Cin / CBK;
+    const int wkd = p.kd, wkh = p.kh, wkw = p.kw;
+    const int taps = wkd * wkh * wkw;
+    const int n_iters_all = taps * cin_steps;
+    const int n_tiles = n_mt * n_nt * p.splits;
+    // workgroup b sits on XCD b % 8: give the workgroups of one XCD consecutive tiles
+    const int G = gridDim.x;
+    const int vb = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+
+    for (int tile = vb; tile < n_tiles; tile += G) {
+        const int nt = tile % n_nt, mt = (tile / n_nt) % n_mt, zs = tile / (n_nt * n_mt);
+        const int m0 = mt * BM, n0 = nt * WS_BN;
+        int it_begin = 0, it_end = n_iters_all;
+        if (p.splits > 1) {
+            it_begin = (int)((int64_t)n_iters_all * zs / p.splits);
+            it_end = (int)((int64_t)n_iters_all * (zs + 1) / p.splits);
+        }
+        const int n_it = it_end - it_begin;
+        const int n_round = (n_it + WSP_DEPTH - 1) / WSP_DEPTH * WSP_DEPTH;
+
+        if (!consumer) {
+            // ---------------- producers (waves 4-7): a quarter of the activation rows and a quarter of the weight tile each ----------------
+            // An LDS-DMA piece (1 KiB) keeps its wave at the issue stage for ~130 cycles on an idle CU and ~250 beside the MFMA stream and the
+            // consumers' fragment reads (s_memtime stamps: the 12 pieces of a step = 3 000 cycles, the split of the step's 16 activation
+            // elements 1 000, in a 4 700-cycle step whose MFMAs need 3 100).  Issued as one block -- as the one-shot tile must, see
+            // lds_store64_unseen -- the two add up and the producers set the step time.  Here every group of weight pieces is followed by the
+            // split of one activation piece: the vector unit works while the texture path digests the pieces already issued.
+            const int64_t shift = (((int64_t)p.pd * p.H + p.ph) * p.W + p.pw) * p.Cin;
+            const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in - shift), 0, WS_OOB, 0x00020000);
+            const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc((void*)wsplit, 0, WS_OOB, 0x00020000);
+            constexpr int AR = BM / 32, BR = 4;                   // activation rows / weight rows per producer thread
+            const int stid = tid - 64 * NCONS;
+            const int akq = stid & 7, arow_ = stid >> 3;
+            const int bkg = stid & 3, brow_ = stid >> 2;
+            unsigned avoff[AR], amask[AR], adst[AR];   // byte offset of the row's own position; bit t CLEAR = tap t reads inside the grid
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int row = arow_ + 32 * i;
+                const int m = m0 + row;
+                const bool vok = m < p.M;
+                const int mm = vok ? m : 0;
+                const int vw = mm % p.OW, vh = (mm / p.OW) % p.OH, vd = mm / (p.OW * p.OH);
+                avoff[i] = (unsigned)(((((int64_t)vd * p.sd) * p.H + vh * p.sh) * p.W + vw * p.sw) * p.Cin * 4 + akq * 16);
+                unsigned msk = 0;
+                if (vok) {
+                    for (int t = 0; t < taps; ++t) {
+                        const int kd = t / (wkh * wkw), kh = (t / wkw) % wkh, kw = t % wkw;
+                        const int id = vd * p.sd + kd - p.pd, ih = vh * p.sh + kh - p.ph, iw = vw * p.sw + kw - p.pw;
+                        if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) msk |= 1u << t;
+                    }
+                }
+                amask[i] = ~msk;
+                adst[i] = (unsigned)((row * CBK + (((akq >> 1) ^ ws_swz(row)) * 8) + (akq & 1) * 4) * 2);
+            }
+            unsigned bvoff[BR];
+#pragma unroll
+            for (int i = 0; i < BR; ++i) {
+                const int row = brow_ + 64 * i, co = n0 + row;
+                bvoff[i] = co < p.Cout ? (unsigned)((co * CBK + ((bkg ^ ws_swz(row)) * 8)) * 2) : WS_OOB;
+            }
+            const int pw4 = wave - NCONS;
+            const unsigned wtile_b = (unsigned)p.Cout * CBK * 2;   // bytes of one weight plane of one K step
+            const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(char*)lds16;
+            int nkd, nkh, nkw, ncs;   // the next tile of the K walk to load: chunk outermost, taps innermost
+            {
+                const int t0 = it_begin % taps;
+                ncs = it_begin / taps;
+                nkd = t0 / (wkh * wkw); nkh = (t0 / wkw) % wkh; nkw = t0 % wkw;
+            }
+            u32x4 ra[WSP_DEPTH][AR];
+            unsigned asoff = 0, tapsh = 31;
+            int bkd = nkd, bkh = nkh, bkw = nkw, bcs = ncs;   // the weight tiles walk the same sequence on their own clock
+            unsigned soff = 0;
+            // tile u of the K walk -> stage u & 1: its weight pieces by LDS-DMA and, between them, the split of the activation pieces in ring
+            // slot `slot` (past the end of the range: the last tile again, into a stage nobody reads)
+            auto stage_tile = [&](int u, int slot, bool live) {
+                if (live) {
+                    const int tap = (bkd * wkh + bkh) * wkw + bkw;
+                    soff = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)tap * cin_steps + bcs) * 3) * wtile_b);
+                    if (++bkw == wkw) {
+                        bkw = 0;
+                        if (++bkh == wkh) {
+                            bkh = 0;
+                            if (++bkd == wkd) { bkd = 0; ++bcs; }
+                        }
+                    }
+                }
+                uint16_t* bst = lds16 + (u & 1) * STAGE + NPL * APL;
+                const unsigned abase = lds0 + (u & 1) * (STAGE * 2);
+                constexpr int BPA = BR / AR;                       // weight row groups issued per activation piece (1 at BM = 128, 2 at BM = 64)
+#pragma unroll
+                for (int i = 0; i < AR; ++i) {
+#pragma unroll
+                    for (int g = i * BPA; g < (i + 1) * BPA; ++g)
+#pragma unroll
+                        for (int pl = 0; pl < NPL; ++pl)
+                            spl_dma16(bres, bst + pl * BPL + (64 * g + pw4 * 16) * CBK, bvoff[g], __builtin_amdgcn_readfirstlane(soff + pl * wtile_b));
+                    const u32x4 uu = ra[slot][i];
+                    uint2 s0, s1, s2;
+                    const float4 xv = make_float4(__uint_as_float(uu.x), __uint_as_float(uu.y), __uint_as_float(uu.z), __uint_as_float(uu.w));
+                    if (ONE) s0 = make_uint2(spl_pack(xv.x, xv.y), spl_pack(xv.z, xv.w));
+                    else spl_split4(xv, s0, s1, s2);
+                    lds_store64_unseen<0>(abase + adst[i], s0);
+                    if (!ONE) {
+                        lds_store64_unseen<APL * 2>(abase + adst[i], s1);
+                        lds_store64_unseen<APL * 4>(abase + adst[i], s2);
+                    }
+                }
+            };
+            auto load_tile = [&](int slot, bool live) {
+                // a tile past the end of this K range (`live` false) re-reads the previous one: legal addresses, staged but never multiplied
+                if (live) {
+                    const int tapw = (nkd * wkh + nkh) * wkw + nkw;
+                    asoff = __builtin_amdgcn_readfirstlane((unsigned)(((((int64_t)nkd * p.H + nkh) * p.W + nkw) * p.Cin + ncs * CBK) * 4));
+                    tapsh = 31 - tapw;
+                    if (++nkw == wkw) {
+                        nkw = 0;
+                        if (++nkh == wkh) {
+                            nkh = 0;
+                            if (++nkd == wkd) { nkd = 0; ++ncs; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < AR; ++i)   // (amask << (31 - tap)) has bit 31 set when this tap reads padding: offset >= 2^31 -> zeros
+                    ra[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(ares, ((amask[i] << tapsh) & WS_OOB) | avoff[i], asoff, 0);
+            };
+
+            __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int d = 0; d < WSP_DEPTH; ++d) load_tile(d, d < n_it);
+            stage_tile(0, 0, n_it > 0);
+            load_tile(0, WSP_DEPTH < n_it);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR) : "memory");   // weight tile 0 has landed (the AR younger activation loads may fly)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // ... and the split's LDS stores
+            __syncthreads();                                              // the consumers arrive here when their epilogue is out
+            for (int j0 = 0; j0 < n_round; j0 += WSP_DEPTH) {
+#pragma unroll
+                for (int d = 0; d < WSP_DEPTH; ++d) {   // tile j0 + d is being multiplied; stage tile j0 + d + 1 (its stage was released by the barrier
+                    stage_tile(j0 + d + 1, (d + 1) % WSP_DEPTH, j0 + d + 1 < n_it);
+                    load_tile((d + 1) % WSP_DEPTH, j0 + d + 1 + WSP_DEPTH < n_it);
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
+            }
+        } else {
+            // ---------------- consumers ----------------
+            f32x4v acc[4][NTB];   // 16 x 16 tiles of the wave's 64 x WNC
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < NTB; ++b) acc[a][b] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+            const int frow = lane & 15, fc = lane >> 4;
+            const int kc = (fc ^ ws_swz(frow)) * 8;
+            const int aoff = (wm * 64 + frow) * CBK + kc;
+            const int boff = NPL * APL + (wn * WNC + frow) * CBK + kc;
+            __syncthreads();
+            for (int j = 0; j < n_round; ++j) {
+                if (j < n_it) {
+                    const uint16_t* st = lds16 + (j & 1) * STAGE;
+                    bf16x8 fa[NPL][4], fb[NPL][NTB];
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) fa[pl][t] = *reinterpret_cast<const bf16x8*>(st + aoff + pl * APL + t * 16 * CBK);
+#pragma unroll
+                        for (int t = 0; t < NTB; ++t) fb[pl][t] = *reinterpret_cast<const bf16x8*>(st + boff + pl * BPL + t * 16 * CBK);
+                    }
+#pragma unroll
+                    for (int order = NPL - 1; order >= 0; --order)
+                        if (order <= p.max_order)
+#pragma unroll
+                        for (int pa = 0; pa <= order; ++pa) {
+                            const int pb = order - pa;
+#pragma unroll
+                            for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                                for (int tb = 0; tb < NTB; ++tb)
+                                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pa][ta], fb[pb][tb], acc[ta][tb], 0, 0, 0);
+                        }
+                }
+                __syncthreads();
+            }
+            // ---- epilogue, consumers only, straight from the C layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg ----
+            const bool raw = p.splits > 1;
+            float* dst = raw ? p.partial + (int64_t)zs * p.M * p.Cout : p.out;
+            const unsigned obytes = (unsigned)((int64_t)p.M * p.Cout * 4);
+            const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, obytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.out), 0,
+                                                                                  p.res_up2 ? (unsigned)((int64_t)p.OD * p.RH * p.RW * p.Cout * 4) : obytes, 0x00020000);
+            const int rowl = m0 + wm * 64 + 4 * (lane >> 4);      // + 16 ta + r
+            const bool has_res = !raw && p.res != nullptr;
+            // nearest-x2 residual: its row is a function of the output row (4 x 4 of them per lane, the same for every column tile)
+            unsigned rrow[4][4];
+            if (has_res && p.res_up2) {
+#pragma unroll
+                for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = rowl + 16 * ta + r;
+                        const int ow = m % p.OW, oh = (m / p.OW) % p.OH, od = m / (p.OW * p.OH);
+                        rrow[ta][r] = m < p.M ? (unsigned)((((int64_t)od * p.RH + (oh >> 1)) * p.RW + (ow >> 1)) * p.Cout * 4) : WS_OOB;
+                    }
+            }
+#pragma unroll
+            for (int tb = 0; tb < NTB; ++tb) {
+                const int cbase = n0 + wn * WNC + tb * 16;
+                if (cbase >= p.Cout) continue;                    // Cout % 16 == 0: a column tile is all inside or all outside
+                const int co = cbase + (lane & 15);
+                const float sc = (!raw && p.scale) ? p.scale[co] : 1.0f, sh = (!raw && p.scale) ? p.shift[co] : 0.0f;
+                const unsigned vo = (unsigned)(((int64_t)rowl * p.Cout + co) * 4);
+                float rr[4][4];
+#pragma unroll
+                for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (!has_res) { rr[ta][r] = 0.0f; continue; }
+                        if (p.res_up2) {
+                            rr[ta][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rres, rrow[ta][r] | (unsigned)(co * 4), 0, 0));
+                        } else {
+                            const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((16 * ta + r) * p.Cout * 4));
+                            rr[ta][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rres, vo, so, 0));
+                        }
+                    }
+#pragma unroll
+                for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((16 * ta + r) * p.Cout * 4));
+                        float v = acc[ta][tb][r];
+                        if (!raw) {
+                            if (p.scale) v = v * sc + sh;
+                            if (p.relu == 2) v = fmaxf(v, 0.f);
+                            if (has_res) v = v + rr[ta][r];
+                            if (p.relu == 1) v = fmaxf(v, 0.f);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, vo, so, 0);
+                    }
+            }
+        }
+    }
+}
+
+template <int BM, int NCONS>
+static int split_launch_wsp(const Conv3dParams& p, hipStream_t st, const char* fn) {
+    const int taps = p.kd * p.kh * p.kw;
+    NDET_REQUIRE(!p.transposed, NDET_E_UNSUPPORTED, "%s: the persistent 128x256 tile does not take transposed convolutions", fn);
+    NDET_REQUIRE(taps <= 32, NDET_E_UNSUPPORTED, "%s: the persistent 128x256 tile supports at most 32 taps", fn);
+    NDET_REQUIRE(p.Cout % 16 == 0, NDET_E_UNSUPPORTED, "%s: the persistent 128x256 tile needs Cout %% 16 == 0", fn);
+    NDET_REQUIRE((int64_t)p.D * p.H * p.W * p.Cin * 4 < ((int64_t)1 << 31) && (int64_t)taps * p.Cin * p.Cout * 6 < ((int64_t)1 << 31) &&
+                     ((int64_t)p.M + 128) * p.Cout * 4 < ((int64_t)1 << 31),
+                 NDET_E_UNSUPPORTED, "%s: the persistent 128x256 tile addresses at most 2 GB per operand", fn);
+    const int n_mt = (p.M + BM - 1) / BM, n_nt = (p.Cout + WS_BN - 1) / WS_BN;
+    const int64_t n_tiles = (int64_t)n_mt * n_nt * p.splits;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 256;
+        else n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = (int)(n_tiles < n_cu ? n_tiles : n_cu);
+    const bool one = p.max_order == 0;
+    const size_t lds = (size_t)2 * (one ? 1 : 3) * (BM + WS_BN) * CBK * sizeof(uint16_t);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[one]) {
+        hipError_t e = one ? hipFuncSetAttribute((const void*)k_conv_split_wsp<true, BM, NCONS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                           : hipFuncSetAttribute((const void*)k_conv_split_wsp<false, BM, NCONS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
+        attr_set[one] = true;
+    }
+    if (one) hipLaunchKernelGGL((k_conv_split_wsp<true, BM, NCONS>), dim3(grid), dim3(64 * (NCONS + 4)), lds, st, p, (const uint16_t*)p.w, n_mt, n_nt);
+    else hipLaunchKernelGGL((k_conv_split_wsp<false, BM, NCONS>), dim3(grid), dim3(64 * (NCONS + 4)), lds, st, p, (const uint16_t*)p.w, n_mt, n_nt);
+    return NDET_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // Halo-stationary tile for stride-1 "same" convolutions with more than one tap (3x3 of the backbone / FPN, 3x3x3 of the
 // neck).  A partner wave gets about one VALU issue slot per MFMA on its SIMD, and the activation split costs 4.5 VALU
 // instructions per element: splitting the A tile anew for every tap (the tiles above) makes the producers the limiter.
@@ -1330,6 +1654,9 @@ int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn)
         case 128: rc = p.max_order == 0 ? split_launch_tile<128, 128, 2, 2, true>(p, st, fn) : split_launch_tile<128, 128, 2, 2>(p, st, fn); break;
         case 12864: rc = p.max_order == 0 ? split_launch_tile<128, 64, 2, 2, true>(p, st, fn) : split_launch_tile<128, 64, 2, 2>(p, st, fn); break;
         case 128256: rc = split_launch_ws(p, st, fn); break;
+        case 129256: rc = split_launch_wsp<128, 4>(p, st, fn); break;     // persistent form of 128256
+        case 129257: rc = split_launch_wsp<128, 8>(p, st, fn); break;     // ... with eight consumer waves (two per SIMD, 64 x 64 each)
+        case 129064: rc = split_launch_wsp<64, 4>(p, st, fn); break;      // ... with 64-row tiles
         case 3128: rc = p.max_order == 0 ? split_launch_halo<4, 2, 2>(p, st, fn) : split_launch_halo<4, 2>(p, st, fn); break;
         case 3256: rc = p.max_order == 0 ? split_launch_halo<8, 2, 2>(p, st, fn) : split_launch_halo<8, 2>(p, st, fn); break;
         case 3257: rc = p.max_order == 0 ? split_launch_halo<4, 4, 2>(p, st, fn) : split_launch_halo<4, 4>(p, st, fn); break;
@@ -1478,7 +1805,7 @@ static int conv_split_entry(const char* fn, int max_order, float xscale, const f
     NDET_REQUIRE(in && w_planes && out && kernel && stride && pad, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
     NDET_REQUIRE((scale == nullptr) == (shift == nullptr), NDET_E_INVALID, "%s: scale and shift go together", fn);
-    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128 || tile == 12864 || tile == 128256 || tile == 3128 || tile == 3256 || tile == 3257 ||
+    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128 || tile == 12864 || tile == 128256 || tile == 129256 || tile == 129257 || tile == 129064 || tile == 3128 || tile == 3256 || tile == 3257 ||
                                           tile == 100064 || tile == 100128 || tile == 112864 ||
                                           (xscale > 0.0f && (tile == 4128 || tile == 4256 || tile == 4257))), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
     NDET_REQUIRE(Cin % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);

@@ -235,6 +235,75 @@ def test_split_conv_wave_specialised_tile(device, cin, cout, grid, k, stride, tr
     assert float((got.cpu() - ref).abs().max()) <= 2e-5 * scale
 
 
+WSP_CASES = [
+    # cin, cout, grid, k, stride, relu, residual (0 none / 1 plain / 2 nearest-x2 upsampled), splits, tile   (persistent wave-specialised tiles)
+    (64, 256, (9, 8, 6), 3, 1, 1, 1, 1, 129256),        # M = 432: ragged last M tile, padding taps everywhere
+    (96, 304, (7, 6, 5), 3, 2, 0, 0, 1, 129256),        # Cout past one N tile (304 = 256 + 48), stride 2
+    (128, 256, (6, 6, 4), 3, 1, 2, 1, 3, 129256),       # split-K + ReLU before the residual
+    (32, 256, (3, 12, 16), 1, 1, 1, 0, 1, 129256),      # 1x1x1, a single K step
+    (256, 512, (1, 40, 52), 1, 1, 1, 1, 1, 129256),     # 2 080 rows x 512: 17 x 2 tiles over the persistent grid, 8 K steps
+    (64, 256, (1, 21, 30), 1, 1, 0, 2, 1, 129256),      # FPN lateral: nearest-x2 upsampled residual, odd map height
+    (128, 256, (1, 150, 200), 1, 1, 1, 1, 1, 129256),   # 30 000 rows: more tiles than CUs, every workgroup walks several
+    (64, 256, (9, 8, 6), 3, 1, 1, 1, 1, 129064),        # the same set on 64-row tiles
+    (96, 304, (7, 6, 5), 3, 2, 0, 0, 1, 129064),
+    (128, 256, (6, 6, 4), 3, 1, 2, 1, 3, 129064),
+    (32, 256, (3, 12, 16), 1, 1, 1, 0, 1, 129064),
+    (256, 512, (1, 40, 52), 1, 1, 1, 1, 1, 129064),
+    (64, 256, (1, 21, 30), 1, 1, 0, 2, 1, 129064),
+    (1024, 256, (1, 150, 100), 1, 1, 1, 0, 2, 129064),  # stage-3 conv1 shape (15 000 rows, 32 K steps), split-K 2
+    (64, 256, (9, 8, 6), 3, 1, 1, 1, 1, 129257),        # the same set with eight consumer waves
+    (96, 304, (7, 6, 5), 3, 2, 0, 0, 1, 129257),
+    (128, 256, (6, 6, 4), 3, 1, 2, 1, 3, 129257),
+    (32, 256, (3, 12, 16), 1, 1, 1, 0, 1, 129257),
+    (256, 512, (1, 40, 52), 1, 1, 1, 1, 1, 129257),
+    (64, 256, (1, 21, 30), 1, 1, 0, 2, 1, 129257),
+    (128, 256, (1, 150, 200), 1, 1, 1, 1, 1, 129257),
+]
+
+
+@pytest.mark.parametrize("cin,cout,grid,k,stride,relu,res_mode,splits,tile", WSP_CASES)
+def test_split_conv_persistent_wave_specialised_tile(device, cin, cout, grid, k, stride, relu, res_mode, splits, tile):
+    """k_conv_split_wsp (tile codes 129256 / 129064): one workgroup per CU walks a list of tiles, the consumers store from the MFMA's C layout
+    while the producers stage the next tile.  Against the fp32 reference, and BIT-IDENTICAL to the one-shot tile 128256 (same K walk, same
+    epilogue arithmetic)."""
+    from nerfdet_amd import conv3d
+    torch.manual_seed(cin + cout + k)
+    two_d = res_mode == 2
+    conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=False) if two_d else nn.Conv3d(cin, cout, k, stride, k // 2, bias=False)
+    bn = (nn.BatchNorm2d if two_d else nn.BatchNorm3d)(cout).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+    x = torch.randn(*grid, cin)
+    with torch.no_grad():
+        if two_d:                                # FPN lateral: (N,H,W,C) maps, residual (N, ceil(OH/2), ceil(OW/2), Cout) read at (h >> 1, w >> 1)
+            y = bn(conv(x.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)
+            n, oh, ow = y.shape[:3]
+            up = torch.randn(n, (oh + 1) // 2, (ow + 1) // 2, cout)
+            y = y + up[:, torch.arange(oh) // 2][:, :, torch.arange(ow) // 2]
+            ref = F.relu(y) if relu == 1 else y
+        else:
+            probe = _ref(x, conv, bn)
+            res = torch.randn_like(probe) if res_mode == 1 else None
+            ref = _ref(x, conv, bn, res, relu)
+        pk = conv3d.packed([conv.to(device)], bn.to(device))
+        prev = conv3d.set_arithmetic("bf16x3")
+        try:
+            if two_d:
+                kw = dict(residual=up.to(device), residual_up2=True, relu=relu)
+                got = conv3d.conv2d_nhwc(x.to(device), pk, tile=tile, **kw)
+                one_shot = conv3d.conv2d_nhwc(x.to(device), pk, tile=128256, **kw)
+            else:
+                kw = dict(residual=None if res is None else res.to(device), relu=relu, splits=splits)
+                got = conv3d.conv3d_ndhwc(x.to(device), pk, tile=tile, **kw)
+                one_shot = conv3d.conv3d_ndhwc(x.to(device), pk, tile=128256, **kw)
+        finally:
+            conv3d.set_arithmetic(prev)
+    assert got.shape == ref.shape
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got.cpu() - ref).abs().max()) <= 2e-5 * scale
+    assert torch.equal(got, one_shot), "the persistent tile must reproduce the one-shot tile bit for bit"
+
+
 HALO_CASES = [
     # cin, cout, grid (D,H,W), kernel (kd,kh,kw), relu, residual, splits, tile   (halo-stationary tiles of the bf16x3 kernel)
     (64, 128, (8, 8, 8), (3, 3, 3), 1, True, 1, 3128),        # exact patches

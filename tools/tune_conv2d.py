@@ -52,7 +52,11 @@ def main():
         C3.set_arithmetic(sys.argv[1])
     if len(sys.argv) > 4:          # tune_conv2d.py <arithmetic> <n_views> <H> <W> [first]
         LAYERS = (first_block_layers if len(sys.argv) > 5 else layers_for)(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
-    tiles = (64, 128, 12864, 128256, 3128, 3256, 3257, 100064, 100128, 112864) if C3.ARITHMETIC in ("bf16x3", "bf16") else (64, 128)
+    tiles = (64, 128, 12864, 128256, 129256, 129257, 129064, 3128, 3256, 3257, 100064, 100128, 112864) if C3.ARITHMETIC in ("bf16x3", "bf16") else (64, 128)
+    if os.environ.get("TUNE_TILES"):
+        tiles = tuple(int(t) for t in os.environ["TUNE_TILES"].split(","))
+    if os.environ.get("TUNE_LAYERS"):
+        LAYERS = [l for l in LAYERS if any(k in l[0] for k in os.environ["TUNE_LAYERS"].split(","))]
     print("arithmetic", C3.ARITHMETIC, flush=True)
     dev = torch.device("cuda")
     tot_best = tot_auto = 0.0
@@ -79,6 +83,7 @@ def main():
                 t = run(tile=tile, splits=splits)
             except Exception:
                 continue
+            if os.environ.get("TUNE_VERBOSE"): print(f"    {name:30s} tile {tile:6d} s={splits:2d} {t*1e3:8.1f} us", flush=True)
             if best is None or t < best[0]: best = (t, tile, splits)
         print("TUNED_JSON", __import__("json").dumps(dict(key=[nhw[0]*oh*ow, cout, k*k*(cin//32), 0], tile=best[1], splits=best[2], us=best[0]*1e3, name=name)), flush=True)
         ta = run()
