@@ -79,11 +79,11 @@ def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: 
     """Tile (64 = 64x64, 128 = 128x128, 12864 = 128 rows x 64 channels, 128256 = wave-specialised 128 rows x 256 channels, 129256 / 129064 = its
     persistent form with 128- / 64-row tiles, 3128 / 3256 / 3257 = halo-stationary 128-voxel patch x 128 / 256 channels) and split-K factor for the
     bf16x3 kernel."""
-    if tile == 0 and splits == 0:
+    if tile == 0 and splits in (0, 1):     # splits == 1: the caller cannot split K (transposed, upsampled residual): the table's tile, unsplit
         key = (m, cout, k_iters, int(transposed))
         hit = (TUNED_BF16.get(key) if ARITHMETIC == "bf16" else None) or TUNED_SPLIT.get(key)
         if hit is not None:
-            return hit
+            return hit if splits == 0 else (hit[0], 1)
     if tile == 0:   # shapes outside the measured table: the pattern the sweeps showed
         mt = (m + 127) // 128
         big = mt * ((cout + 127) // 128)

@@ -102,7 +102,8 @@ __device__ __forceinline__ void conv_split_mainloop(const Conv3dParams& p, const
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const ConvBlock blk = conv_block(p);
+    const int m0 = blk.x * BM, n0 = blk.y * BN;
     const int akq = tid & 7, arow_ = tid >> 3;   // A: 4-k quad and first row
     const int bkg = tid & 3, brow_ = tid >> 2;   // B: 8-k octet and first row
 
@@ -112,9 +113,9 @@ __device__ __forceinline__ void conv_split_mainloop(const Conv3dParams& p, const
     int it_begin = 0, it_end = n_iters_all;
     ztap = 0;
     if (p.transposed) {
-        ztap = blockIdx.z;
+        ztap = blk.z;
     } else if (p.splits > 1) {
-        const int s = blockIdx.z;
+        const int s = blk.z;
         it_begin = (int)((int64_t)n_iters_all * s / p.splits);
         it_end = (int)((int64_t)n_iters_all * (s + 1) / p.splits);
     }
@@ -263,7 +264,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const ConvBlock blk = conv_block(p);
+    const int m0 = blk.x * BM, n0 = blk.y * BN;
     f32x16 acc[MT][NT];
     int ztap;
     conv_split_mainloop<BM, BN, WGM, WGN, ONE>(p, wsplit, lds16, acc, ztap);
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
                         Cs[(ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CLDC + wn * WN + tb * 32 + (lane & 31)] = acc[ta][tb][r];
         }
         __syncthreads();
-        conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, ztap, blockIdx.z);
+        conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, ztap, blk.z);
         __syncthreads();
     }
 }
@@ -731,7 +733,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the role branch and everything under it stay wave-uniform
     const bool consumer = wave < 4;
     const int wm = (wave & 3) >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * WS_BM, n0 = blockIdx.y * WS_BN;
+    const ConvBlock blk = conv_block(p);
+    const int m0 = blk.x * WS_BM, n0 = blk.y * WS_BN;
     const int stid = tid & 255;
     const int akq = stid & 7, arow_ = stid >> 3;
     const int bkg = stid & 3, brow_ = stid >> 2;
@@ -743,9 +746,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
     int it_begin = 0, it_end = n_iters_all;
     int ztap = 0;
     if (p.transposed) {
-        ztap = blockIdx.z;
+        ztap = blk.z;
     } else if (p.splits > 1) {
-        const int s = blockIdx.z;
+        const int s = blk.z;
         it_begin = (int)((int64_t)n_iters_all * s / p.splits);
         it_end = (int)((int64_t)n_iters_all * (s + 1) / p.splits);
     }
@@ -947,7 +950,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
                         Cs[(ta * 16 + (lane >> 4) * 4 + r) * CLDC + wn * 128 + tb * 16 + (lane & 15)] = acc[ta][tb][r];
         }
         __syncthreads();
-        conv_store_rows<WS_BN, 512>(p, Cs, CLDC, m0 + h * 64, 64, n0, tid, ztap, blockIdx.z);
+        conv_store_rows<WS_BN, 512>(p, Cs, CLDC, m0 + h * 64, 64, n0, tid, ztap, blk.z);
         __syncthreads();
     }
 }
@@ -1356,9 +1359,10 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool consumer = wave < NCONS;
     const int wm = (wave % NCONS) / WGN, wn = (wave % NCONS) % WGN;
-    const int n0 = blockIdx.y * BN;
+    const ConvBlock blk = conv_block(p);
+    const int n0 = blk.y * BN;
     const int TH = 1 << g.lth, TW = 1 << g.ltw;
-    int pb = blockIdx.x;
+    int pb = blk.x;
     const int pwi = pb % g.npw; pb /= g.npw;
     const int phi = pb % g.nph;
     const int pdi = pb / g.nph;
@@ -1367,8 +1371,8 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
     const int nch_all = p.Cin / CBK;
     int cb = 0, ce = nch_all;
     if (p.splits > 1) {
-        cb = (int)((int64_t)nch_all * blockIdx.z / p.splits);
-        ce = (int)((int64_t)nch_all * (blockIdx.z + 1) / p.splits);
+        cb = (int)((int64_t)nch_all * blk.z / p.splits);
+        ce = (int)((int64_t)nch_all * (blk.z + 1) / p.splits);
     }
     const int nch = ce - cb;
     const int T = g.T, Tin = g.Tin;
@@ -1562,7 +1566,7 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
                         Cs[(ta * 16 + (lane >> 4) * 4 + r) * CLDC + wn * (16 * NT16) + tb * 16 + (lane & 15)] = acc[ta][tb][r];
         }
         __syncthreads();
-        conv_store_rows_mapped<BN, NTHR>(p, Cs, CLDC, 64, n0, tid, 0, blockIdx.z, HaloRowMap{h * 64, g.ltw, g.lth, d0, h0, w0, p.OD, p.OH, p.OW});
+        conv_store_rows_mapped<BN, NTHR>(p, Cs, CLDC, 64, n0, tid, 0, blk.z, HaloRowMap{h * 64, g.ltw, g.lth, d0, h0, w0, p.OD, p.OH, p.OW});
         __syncthreads();
     }
 }
@@ -1638,6 +1642,9 @@ static int split_launch_tile(const Conv3dParams& p, hipStream_t st, const char* 
     return NDET_OK;
 }
 
+#ifndef NDET_ORDER_DEFAULT
+#define NDET_ORDER_DEFAULT -1      // -1: chosen per launch below; 0 / 1 / 2 force one order (measurement builds)
+#endif
 int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn) {
     p.direct = 0;
     if (tile >= 100000 && (tile - 100000 == 64 || tile - 100000 == 128 || tile - 100000 == 12864)) {   // 100064 / 100128 / 112864: direct epilogue
@@ -1648,6 +1655,19 @@ int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn)
     }
     const int64_t big_tiles = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     if (tile == 0) tile = (big_tiles >= 192 && p.Cout >= 128) ? 128 : 64;
+    {   // which operand is worth keeping in one XCD's L2 (Conv3dParams::order): the bytes its re-reads would otherwise fetch again
+        const int tm = tile == 64 ? 64 : 128, tn = tile == 64 || tile == 12864 ? 64 : (tile == 128 || tile == 3128 || tile == 4128 ? 128 : 256);
+        const int64_t mt = (p.M + tm - 1) / tm, nt = (p.Cout + tn - 1) / tn;
+        const int64_t taps = p.transposed ? 1 : (int64_t)p.kd * p.kh * p.kw;
+        const int64_t w_bytes = taps * p.Cin * p.Cout * 6, a_bytes = (int64_t)p.M * p.Cin * 4 * (p.sd * p.sh * p.sw);
+        const int64_t save_w = (mt - 1) * w_bytes, save_a = (nt - 1) * a_bytes;
+        p.order = NDET_ORDER_DEFAULT;
+        if (NDET_ORDER_DEFAULT < 0) {
+            p.order = 0;
+            if (!p.transposed && mt > 1 && nt * p.splits > 1 && save_w > save_a && w_bytes > (8 << 20)) p.order = 1;
+            else if (!p.transposed && nt > 1 && mt >= 16 && save_a > save_w && a_bytes > (8 << 20)) p.order = 2;
+        }
+    }
     int rc;
     switch (tile) {
         case 64: rc = p.max_order == 0 ? split_launch_tile<64, 64, 2, 2, true>(p, st, fn) : split_launch_tile<64, 64, 2, 2>(p, st, fn); break;

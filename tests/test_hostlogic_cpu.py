@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_tiling_tables_and_heuristics_are_well_formed():
     from nerfdet_amd import conv3d
     from nerfdet_amd.conv_tuning import TUNED, TUNED_SPLIT
-    f32_tiles, split_tiles = {64, 128}, {64, 128, 12864, 128256, 3128, 3256, 3257}
+    f32_tiles, split_tiles = {64, 128}, {64, 128, 12864, 128256, 129256, 129257, 129064, 3128, 3256, 3257}
     for table, tiles in ((TUNED, f32_tiles), (TUNED_SPLIT, split_tiles)):
         assert len(table) >= 20
         for (m, cout, k_iters, tr), (tile, splits) in table.items():
