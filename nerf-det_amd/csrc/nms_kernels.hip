@@ -427,7 +427,12 @@ __global__ __launch_bounds__(1024) void k_select_candidates(const SelectLevels l
 // (its order inside a level differs: voxel order here, descending score there; the NMS sorts by score anyway).
 // counts[l] = candidates of level l after the cut, counts[n_levels] = total, counts[n_levels + 1] = survivors before any cut.
 __global__ __launch_bounds__(1024) void k_select_candidates_topk(const SelectLevels lv, float thr, int nms_pre, float* __restrict__ o_best,
-                                                                 int64_t* __restrict__ o_label, float* __restrict__ o_boxes, int* __restrict__ counts) {
+                                                                 int64_t* __restrict__ o_label, float* __restrict__ o_boxes, int* __restrict__ counts,
+                                                                 int lds_cap) {
+    // a level's scores are walked five times (threshold count, three radix rounds, compaction) by ONE workgroup: each walk from global
+    // memory is a chain of dependent-latency loads (25 per thread at 25 600 voxels).  The first walk parks them in LDS (16-byte loads, up
+    // to lds_cap floats); levels that do not fit keep reading global memory.
+    extern __shared__ __attribute__((aligned(16))) float lsc[];
     __shared__ int wave_cnt[16], wave_eq[16];
     __shared__ int base_s, eq_s, raw_s, sel_need;
     __shared__ unsigned sel_prefix;
@@ -437,10 +442,27 @@ __global__ __launch_bounds__(1024) void k_select_candidates_topk(const SelectLev
     __syncthreads();
     for (int l = 0; l < lv.n_levels; ++l) {
         const int n_l = lv.n[l];
-        const float* __restrict__ best = lv.best[l];
+        const float* __restrict__ gbest = lv.best[l];
+        const bool cached = n_l <= lds_cap && (((uintptr_t)gbest) & 15) == 0;
+        auto best_at = [&](int i) -> float { return cached ? lsc[i] : gbest[i]; };
         // ---- survivors of the threshold ----
         int c = 0;
-        for (int i = tid; i < n_l; i += 1024) c += best[i] > thr ? 1 : 0;
+        if (cached) {
+            __syncthreads();                               // the previous level's readers are done with lsc
+            const int n4 = n_l >> 2;
+            for (int i = tid; i < n4; i += 1024) {
+                const float4 v = reinterpret_cast<const float4*>(gbest)[i];
+                reinterpret_cast<float4*>(lsc)[i] = v;
+                c += (v.x > thr ? 1 : 0) + (v.y > thr ? 1 : 0) + (v.z > thr ? 1 : 0) + (v.w > thr ? 1 : 0);
+            }
+            for (int i = 4 * n4 + tid; i < n_l; i += 1024) {
+                const float v = gbest[i];
+                lsc[i] = v;
+                c += v > thr ? 1 : 0;
+            }
+        } else {
+            for (int i = tid; i < n_l; i += 1024) c += gbest[i] > thr ? 1 : 0;
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
         if (lane == 0) wave_cnt[wave] = c;
@@ -459,7 +481,7 @@ __global__ __launch_bounds__(1024) void k_select_candidates_topk(const SelectLev
                 for (int b = tid; b < 2048; b += 1024) hist[b] = 0;
                 __syncthreads();
                 for (int i = tid; i < n_l; i += 1024) {
-                    const float v = best[i];
+                    const float v = best_at(i);
                     if (v > thr) {
                         const unsigned key = __float_as_uint(v);
                         if (bits_done == 0 || (key >> (32 - bits_done)) == prefix) atomicAdd(&hist[(key >> shift) & ((1u << width) - 1u)], 1);
@@ -504,7 +526,7 @@ __global__ __launch_bounds__(1024) void k_select_candidates_topk(const SelectLev
         const int i_lo = min(tid * per, n_l), i_hi = min(i_lo + per, n_l);
         int n_gt = 0, n_eq = 0;
         for (int i = i_lo; i < i_hi; ++i) {
-            const float v = best[i];
+            const float v = best_at(i);
             if (v > thr) {
                 const unsigned key = __float_as_uint(v);
                 n_gt += key > K ? 1 : 0;
@@ -536,7 +558,7 @@ __global__ __launch_bounds__(1024) void k_select_candidates_topk(const SelectLev
         const int off0 = block_exclusive(n_gt + eq_keep, wave_cnt, tot_keep);
         int o = level_base + off0, eq_left = eq_keep;
         for (int i = i_lo; i < i_hi; ++i) {
-            const float v = best[i];
+            const float v = best_at(i);
             if (!(v > thr)) continue;
             const unsigned key = __float_as_uint(v);
             bool keep = key > K;
@@ -569,8 +591,20 @@ extern "C" int ndet_select_candidates_topk(int n_levels, const float* const* bes
         NDET_REQUIRE(best[l] && label[l] && boxes[l] && n[l] > 0, NDET_E_INVALID, "%s: level %d: null pointer / empty", fn, l);
         lv.best[l] = best[l]; lv.label[l] = label[l]; lv.boxes[l] = boxes[l]; lv.n[l] = n[l];
     }
-    hipLaunchKernelGGL(k_select_candidates_topk, dim3(1), dim3(1024), 0, (hipStream_t)stream, lv, score_thr, nms_pre, out_best, out_label, out_boxes,
-                       counts);
+    // LDS for the scores of the largest level that fits (36 000 floats = 141 KB beside the 8 KB histogram); larger levels read global memory
+    constexpr int LDS_CAP = 36000;
+    int cap = 0;
+    for (int l = 0; l < n_levels; ++l)
+        if (n[l] <= LDS_CAP && n[l] > cap) cap = n[l];
+    const size_t lds = (size_t)((cap + 3) / 4 * 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_select_candidates_topk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_CAP * sizeof(float)));
+        NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_select_candidates_topk, dim3(1), dim3(1024), lds, (hipStream_t)stream, lv, score_thr, nms_pre, out_best, out_label, out_boxes,
+                       counts, cap);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
