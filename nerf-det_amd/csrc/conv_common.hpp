@@ -30,8 +30,7 @@ struct Conv3dParams {
                           // no barriers; needs splits == 1, no transposed / upsampled-residual mode, Cout % 32 == 0, output < 4 GB)
     int order = 0;        // bf16x3 grid kernels: which workgroups meet in one XCD's L2 (workgroup b is dispatched to XCD b % 8).  0: grid order (row tiles
                           // fastest).  1: the row tiles of one (column tile, K split) weight slice run on one XCD -- layers whose weights outweigh their
-                          // activations (the 20x20x8 / 10x10x4 neck levels: 42 - 170 MB of weight planes, re-streamed from HBM by every XCD in grid
-                          // order).  2: the column tiles of one row tile run back to back on one XCD (wide 1x1 layers: the activation rows are read once)
+                          // activations (the 20x20x8 / 10x10x4 neck levels: 42 - 170 MB of weight planes, re-streamed from HBM by every XCD in grid order)
     float xscale;         // fp16-pair tiles: power of two the activations are multiplied by while they are split (its inverse, and the
                           // weight scale's, are folded into `scale` by the caller)
 };
@@ -50,17 +49,6 @@ __device__ __forceinline__ ConvBlock conv_block(const Conv3dParams& p) {
         const int s = gy * gz, l = b.x + gx * (b.y + gy * b.z);
         const int slice = l % s;
         b.x = l / s; b.y = slice % gy; b.z = slice / gy;
-    } else if (p.order == 2) {
-        const int l = b.x + gx * b.y;                       // within this split's slab
-        const int full = (gx >> 3) * 8 * gy;                // workgroups in whole blocks of 8 row tiles x gy column tiles
-        if (l < full) {
-            b.x = (l / (8 * gy)) * 8 + (l & 7);
-            b.y = (l >> 3) % gy;
-        } else {
-            const int r = gx & 7, l2 = l - full;            // the ragged last block: r row tiles
-            b.x = (gx >> 3) * 8 + l2 % r;
-            b.y = l2 / r;
-        }
     }
     return b;
 }

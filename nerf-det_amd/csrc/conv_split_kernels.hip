@@ -1643,7 +1643,7 @@ static int split_launch_tile(const Conv3dParams& p, hipStream_t st, const char* 
 }
 
 #ifndef NDET_ORDER_DEFAULT
-#define NDET_ORDER_DEFAULT -1      // -1: chosen per launch below; 0 / 1 / 2 force one order (measurement builds)
+#define NDET_ORDER_DEFAULT -1      // -1: chosen per launch below; 0 / 1 force one order (measurement builds)
 #endif
 int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn) {
     p.direct = 0;
@@ -1665,7 +1665,7 @@ int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn)
         if (NDET_ORDER_DEFAULT < 0) {
             p.order = 0;
             if (!p.transposed && mt > 1 && nt * p.splits > 1 && save_w > save_a && w_bytes > (8 << 20)) p.order = 1;
-            else if (!p.transposed && nt > 1 && mt >= 16 && save_a > save_w && a_bytes > (8 << 20)) p.order = 2;
+            // (the mirror case -- the column tiles of one row tile on one XCD -- would need (nt - 1) tm 4 > 6 Cout taps: no tile of this family)
         }
     }
     int rc;
