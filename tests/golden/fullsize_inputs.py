@@ -18,6 +18,10 @@ CONFIGS = {
     # BASELINE.json configs[1] / configs[0]: 50 / 10 views 240x320, FPN level 0 = 256 x 60 x 80, 40x40x16 voxels of 0.16x0.16x0.2
     "cfg2": dict(seed=20, n_views=50, channels=256, img_hw=(240, 320), n_voxels=(40, 40, 16), voxel_size=(0.16, 0.16, 0.2), n_sample=4096),
     "cfg1": dict(seed=21, n_views=10, channels=256, img_hw=(240, 320), n_voxels=(40, 40, 16), voxel_size=(0.16, 0.16, 0.2), n_sample=2048),
+    # BASELINE.json configs[4] views and maps (101 views 320x480, FPN level 0 = 256 x 80 x 120) into an 80 x 80 x 4 SLAB of its 80x80x32 grid at its
+    # voxel size: the reference materialises (n_v, C, N) and would need 21 GB per tensor for the whole grid; the slab is a grid of its own
+    # (both sides are handed the same n_voxels and origin), 25 600 voxels seen by up to 101 views (the kernels' second 64-view round)
+    "cfg5slab": dict(seed=22, n_views=101, channels=256, img_hw=(320, 480), n_voxels=(80, 80, 4), voxel_size=(0.08, 0.08, 0.1), n_sample=2048),
 }
 NEAR_TOL = 1e-3        # px: voxels with a view this close to a .5 rounding boundary are all stored
 NEAR_CHANNEL_STEP = 4  # ... with every 4th channel (a neighbouring pixel changes every channel)

@@ -64,7 +64,7 @@ def check_against_reference(g, cnt, volume_cn, glob, alpha, tol):
     return out
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg2"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg5slab"])
 def test_oracle_equals_reference_at_baseline_size(name):
     g, cfg, feats, denorm, mapping, mlp, meta = fullsize_case(name)
     assert O.PINNED_ARITHMETIC

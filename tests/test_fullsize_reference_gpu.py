@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("arithmetic", ["bf16x3", "f32"])
-@pytest.mark.parametrize("name", ["cfg1", "cfg2"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg5slab"])
 def test_extract_volume_equals_reference_at_baseline_size(device, name, arithmetic):
     from nerfdet_amd import conv3d, ops
     from nerfdet_amd.volume import extract_volume
