@@ -13,23 +13,90 @@ GROUPS = ("backbone.layer2", "backbone.layer3", "backbone.layer4", "neck.lateral
           "neck_3d.down_layer_0", "neck_3d.down_layer_1", "neck_3d.down_layer_2", "neck_3d.up_block", "neck_3d.out_block", "bbox_head")
 
 
+def _learnable_scene(device):
+    """tests/test_ddp.py's scene with NeRF targets that can be fitted: one colour and one depth for every target ray (the generator's
+    uniform-random colours and depths leave the two NeRF losses at their noise floor)."""
+    from test_ddp import _scene
+    scene = _scene(0, device)
+    scene["gt_depths"] = torch.full_like(scene["gt_depths"], 2.0)
+    scene["gt_images"] = torch.ones_like(scene["gt_images"]) * torch.tensor([0.3, 0.5, 0.7], device=device)
+    return scene
+
+
 @pytest.mark.timeout(900)
-def test_thirty_steps_on_a_fixed_scene_lower_all_five_losses(device):
-    """Thirty optimizer steps (config:167-173: AdamW 2e-4, backbone x0.1, clip 35) on one scene, every step with its own ray draw and
-    sampling noise as in training; the five losses are read on a FIXED probe -- the same 512 rays, the same noise -- before and after."""
-    from test_ddp import _build, _scene
+def test_each_of_the_five_losses_descends_along_its_own_gradient(device):
+    """First-order check of the whole backward, one loss at a time: with g = d loss_k / d theta from ``backward()``, the step
+    theta - eps g / |g| must lower loss_k, and by eps |g| once eps is small enough for the curvature not to matter, on a fixed probe (same
+    2 048 rays, same sampling noise: the forward has no atomics and is deterministic).  A wrong term anywhere on a loss's path -- scatter
+    kernels, convolution data / weight gradients, BatchNorm, the fused epilogue's backward -- leaves the observed / predicted ratio away
+    from 1 at every step size.  Steps predicted to lower the loss by 1e-2, 1e-3, 1e-4 and 1e-5 of its value are tried (fp32 resolves
+    the last one to ~1 %): four of the losses meet the prediction within 2 - 12 % at the first; the L1 depth loss is sharply curved
+    along the feature directions (0.20, 0.25, 0.50, 0.92 of the prediction as the step shrinks; 1.00 along the MLP's own parameters)."""
+    from test_ddp import _build
+    import nerfdet_amd.rays as R
+    det = _build(device)
+    det.N_rand = 2048
+    scene = _learnable_scene(device)
+    params = [p for p in det.parameters() if p.requires_grad]
+
+    def losses():
+        R.rng = np.random.RandomState(99)
+        torch.manual_seed(7)
+        return det(return_loss=True, **scene)
+
+    def value(out, k):
+        return out[k] if isinstance(out[k], torch.Tensor) else sum(out[k])
+    report = {}
+    for k in LOSSES:
+        det.zero_grad(set_to_none=True)
+        lk = value(losses(), k)
+        l0 = float(lk.detach())
+        lk.backward()
+        grads = [None if p.grad is None else p.grad.detach().clone() for p in params]
+        gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads if g is not None)))
+        assert np.isfinite(gnorm) and gnorm > 0, k
+        ratios = []
+        for frac in (1e-2, 1e-3, 1e-4, 1e-5):
+            eps = frac * max(l0, 1e-3) / gnorm                 # predicted decrease: frac of the loss
+            with torch.no_grad():
+                for p, g in zip(params, grads):
+                    if g is not None:
+                        p.sub_(g * (eps / gnorm))
+                l1 = float(value(losses(), k))
+                for p, g in zip(params, grads):
+                    if g is not None:
+                        p.add_(g * (eps / gnorm))
+            ratios.append((l0 - l1) / (eps * gnorm))
+        report[k] = (l0, ratios)
+    print("descent along the own gradient, observed / predicted decrease at 1e-2 .. 1e-5 of the loss:", {k: (round(a, 5), [round(r, 3) for r in rs]) for k, (a, rs) in report.items()})
+    for k, (l0, ratios) in report.items():
+        assert all(r > 0 for r in ratios[:3]), f"{k} does not fall along its own negative gradient: {ratios}"
+        assert any(0.8 <= r <= 1.2 for r in ratios), f"{k}: the first-order prediction is met at no step size: {ratios}"
+
+
+@pytest.mark.timeout(900)
+def test_thirty_optimizer_steps_on_a_fixed_scene_lower_the_loss(device):
+    """Thirty steps of the reference's optimizer set-up (config:167-173: AdamW 2e-4, backbone x0.1, clip 35) on one scene, every step with
+    its own ray draw and sampling noise; read on a fixed probe before and after.  The total and the three losses that move by tens of
+    per cent in 30 steps must fall.  (Adam's sign-like first steps make the trajectory chaotic under the float atomics' run-to-run noise:
+    the classification loss alone ended between 0.24 and 1.35 from 1.11 in repeated runs, the depth loss within +-1 % of its start -- the
+    per-loss statement is the first-order test above.)"""
+    from test_ddp import _build
     import nerfdet_amd.rays as R
     from nerfdet_amd.train import build_optimizer, train_one_step
     det = _build(device)
     det.N_rand = 512
     opt = build_optimizer(det)
-    scene = _scene(0, device)
+    scene = _learnable_scene(device)
 
     def probe():
+        det.N_rand = 2048
         R.rng = np.random.RandomState(99)
         torch.manual_seed(7)
         with torch.no_grad():
-            return {k: float(v) for k, v in det.train_step(scene)["log_vars"].items()}
+            out = {k: float(v) for k, v in det.train_step(scene)["log_vars"].items()}
+        det.N_rand = 512
+        return out
     first = probe()
     R.rng = np.random.RandomState(234)
     torch.manual_seed(3)
@@ -37,9 +104,9 @@ def test_thirty_steps_on_a_fixed_scene_lower_all_five_losses(device):
     assert all(np.isfinite(h["loss"]) for h in hist)
     last = probe()
     print("fixed scene, probe before -> after 30 steps:", {k: (round(first[k], 4), round(last[k], 4)) for k in first})
-    for k in LOSSES + ("loss",):
+    for k in ("loss", "loss_centerness", "loss_bbox", "loss_nvs"):
         assert last[k] < first[k], f"{k} did not fall: {first[k]:.4f} -> {last[k]:.4f}"
-    assert last["loss"] < 0.9 * first["loss"]
+    assert last["loss_depth"] < 1.03 * first["loss_depth"]
 
 
 @pytest.mark.timeout(900)
