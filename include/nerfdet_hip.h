@@ -290,15 +290,38 @@ int ndet_conv_chain_split(const float* in, const uint16_t* w_planes, int D, int 
                           int Cout, const float* scale3, const float* shift3, const float* residual, int relu3, float* out,
                           int max_order, void* stream);
 
-/* Experimental fp32-class arithmetic for the halo-stationary tiles (stride-1 same-padded multi-tap layers: the 3x3 / 3x3x3
- * convolutions of mmdet3d/models/necks/imvoxelnet.py:22-67,233-260 and of the FPN / ResNet): operands as fp16 PAIRS, three MFMA
- * products per multiply instead of six.  The caller pre-scales both tensors by powers of two towards 2^15 (weights: `scale` of
- * ndet_split_weights_f16x2; activations: `xscale`, applied while they are split) and folds 1 / (xscale * weight scale) into the
- * epilogue's `scale`.  tile: 4128 / 4256 / 4257 (= 3128 / 3256 / 3257 on two planes). */
+/* fp16-PAIR arithmetic of the same convolutions (arith = 1 below): every fp32 operand, pre-scaled by a power of two so that the tensor's
+ * largest magnitude sits in [2^14, 2^15), is written as hi + lo with hi = fp16(x), lo = fp16(x - hi) (2 x 11 significand bits + sign:
+ * |x - hi - lo| <= 2^-23 |x| for every element above ~2^-16 of the tensor's maximum), and a*b is accumulated in fp32 as the THREE products
+ * hi_a hi_b + hi_a lo_b + lo_a hi_b (each exact in fp32; the dropped lo_a lo_b is <= 2^-22 |ab|) -- half the MFMA work of the six-product
+ * bf16x3 scheme, with a measured error against fp64 at or below bf16x3's on every layer shape (three accumulator roundings per K step
+ * instead of six; tests/test_conv3d_gpu.py).  Weights: ndet_split_weights_f16x2 builds the planes (taps, Cin/32, 2, Cout, 32) of
+ * w * scale once per model (scale = a power of two, chosen by the caller from max |w|); activations: the kernels derive their scale on
+ * the device from `in_amax` (max |in|, written by the previous layer's epilogue through its `out_amax`, or by ndet_amax_f32) and undo both
+ * scales in the epilogue -- nothing is synchronised with the host.  Same reference modules as ndet_conv_ndhwc_split
+ * (mmdet3d/models/necks/imvoxelnet.py:36-67,233-260). */
 int ndet_split_weights_f16x2(const float* w_packed, int taps, int Cout, int Cin, float scale, uint16_t* planes, void* stream);
-int ndet_conv_ndhwc_f16x2(const float* in, const uint16_t* w_planes_f16, float* out, int D, int H, int W, int Cin, int Cout,
-                          const int* kernel, const int* stride, const int* pad, const float* scale, const float* shift,
-                          const float* residual, int relu, int splits, int tile, float xscale, void* workspace, void* stream);
+
+/* max |x| over n floats, atomically maxed (as uint bits) into *slot, which the caller zeroed: the `in_amax` of a fp16-pair convolution
+ * whose input no convolution kernel wrote (the voxel volume of nerfdet.py:363-420, the MLP inputs of nerf_mlp.py:200-245). */
+int ndet_amax_f32(const float* x, int64_t n, float* slot, void* stream);
+
+/* ndet_conv_ndhwc_split / ndet_conv_ndhwc_bf16 (necks/imvoxelnet.py:36-67,233-260, imvoxel_head_v2.py:45-49, the backbone behind
+ * nerfdet.py:140) with the arithmetic as an argument: arith 0 = bf16x3 (six products), 1 = fp16 pair (three
+ * products; w_planes from ndet_split_weights_f16x2, `in_amax` required, w_inv_scale = 1 / that call's scale), 2 = bf16 (one product).
+ * out_amax (any arith, may be null): max |out| is maxed into *out_amax (zeroed by the caller) -- the next layer's in_amax. */
+int ndet_conv_ndhwc_arith(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
+                          const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
+                          const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile, int arith,
+                          const float* in_amax, float w_inv_scale, float* out_amax, void* workspace, void* stream);
+
+/* ndet_conv_chain_split with the arithmetic as an argument (as above; w1_inv_scale / w3_inv_scale belong to w_planes / w3_planes).  In the
+ * fp16-pair arithmetic the intermediate's scale is the workgroup's own maximum: it never exists as a whole tensor.  Same reference code
+ * as ndet_conv_chain_split: the bottleneck tail of the backbone called at mmdet3d/models/detectors/nerfdet.py:140. */
+int ndet_conv_chain_arith(const float* in, const uint16_t* w_planes, int D, int H, int W, int Cin, int Cmid, const int* kernel,
+                          const int* stride, const int* pad, const float* scale1, const float* shift1, const uint16_t* w3_planes,
+                          int Cout, const float* scale3, const float* shift3, const float* residual, int relu3, float* out,
+                          int arith, const float* in_amax, float w1_inv_scale, float w3_inv_scale, float* out_amax, void* stream);
 
 /* ResNet stem tail in one pass: BatchNorm(eval) as per-channel scale/shift + ReLU + MaxPool(3, stride 2, pad 1) on the
  * channels-last stem output x (N,H,W,C), C % 4 == 0 -> out (N, (H-1)/2+1, (W-1)/2+1, C).  Third-party mmdet ResNet stem

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .conv3d import bn_relu_maxpool_nhwc, chain_ok, conv2d_chain_nhwc, conv2d_nhwc, packed, stem_conv_bn_relu_maxpool, stem_ok
+from .conv3d import bn_relu_maxpool_nhwc, carry_amax, chain_ok, conv2d_chain_nhwc, conv2d_nhwc, packed, stem_conv_bn_relu_maxpool, stem_ok
 from .conv_train import conv_bn_act, conv_forward
 from .registry import BACKBONES, NECKS
 
@@ -19,7 +19,7 @@ from .registry import BACKBONES, NECKS
 def _nhwc(x):
     """logical (N,C,H,W) -> contiguous (N,H,W,C) (free for channels-last memory)."""
     y = x.permute(0, 2, 3, 1)
-    return y if y.is_contiguous() else y.contiguous()
+    return carry_amax(x, y if y.is_contiguous() else y.contiguous())
 
 
 class Bottleneck(nn.Module):
@@ -180,7 +180,7 @@ class ResNet(nn.Module):
             for blk in getattr(self, f"layer{i + 1}"):
                 x = blk.forward_nhwc(x)
             if i in self.out_indices:
-                outs.append(x.permute(0, 3, 1, 2))  # logical NCHW view of channels-last memory
+                outs.append(carry_amax(x, x.permute(0, 3, 1, 2)))  # logical NCHW view of channels-last memory
         return tuple(outs)
 
     def forward_library(self, x):

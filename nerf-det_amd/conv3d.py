@@ -7,6 +7,7 @@ mmdet3d/models/necks/imvoxelnet.py:36-67,233-260."""
 from __future__ import annotations
 
 import ctypes
+import math
 from ctypes import c_void_p
 from typing import Optional, Sequence
 
@@ -15,23 +16,81 @@ from torch import nn
 
 from . import _lib, trace
 from ._lib import check
-from .conv_tuning import TUNED, TUNED_BF16, TUNED_SPLIT
+from .conv_tuning import TUNED, TUNED_BF16, TUNED_F16, TUNED_SPLIT
 
 # Arithmetic of the convolution kernels: "bf16x3" = fp32 operands split exactly into three bf16 terms, six bf16-MFMA
 # products accumulated in fp32 (csrc/conv_split_kernels.hip; fp32-level error, 16x the MFMA rate per product);
 # "f32" = the fp32-input MFMA kernel (csrc/conv3d_kernels.hip; bit-exact FMA chains);
 # "bf16" = the bf16x3 kernels issuing only the leading product: operands rounded to bf16, fp32 accumulate, fp32 activations in HBM
-# (what bf16 autocast computes; BASELINE.json configs 3 and 5).
+# (what bf16 autocast computes; BASELINE.json configs 3 and 5);
+# "f16x2" = fp32 operands as fp16 PAIRS (hi + lo of the power-of-two pre-scaled tensor, 2 x 11 significand bits + sign), three fp16-MFMA products
+# accumulated in fp32: half the matrix-core work of bf16x3 at the same or a smaller measured error against fp64 (three accumulator
+# roundings per K step instead of six; tests/test_conv3d_gpu.py::test_f16x2_error_not_above_bf16x3).  The activation scale is derived on the
+# device from the input's max |x|, which every convolution epilogue leaves behind for the next layer (the `_ndet_amax` attribute of its output
+# tensor); layers with fewer than F16_MIN_KSTEPS K steps stay on bf16x3 (HBM-bound: nothing to gain), training stays on bf16x3.
 ARITHMETIC = "bf16x3"
+F16_MIN_KSTEPS = 4
+SPLIT_FAMILY = ("bf16x3", "bf16", "f16x2")    # the arithmetics of csrc/conv_split_kernels.hip
 
 
 def set_arithmetic(mode: str) -> str:
     """Select the kernel family for every following convolution launch; returns the previous mode."""
     global ARITHMETIC
-    if mode not in ("f32", "bf16x3", "bf16"):
+    if mode not in ("f32", "bf16x3", "bf16", "f16x2"):
         raise ValueError(f"unknown conv arithmetic {mode!r}")
     prev, ARITHMETIC = ARITHMETIC, mode
     return prev
+
+
+def train_arithmetic() -> str:
+    """What the training kernels (data / weight gradients, nerfdet_amd/conv_train.py) compute in under the current mode."""
+    return "bf16x3" if ARITHMETIC == "f16x2" else ARITHMETIC
+
+
+class _AmaxSlots:
+    """One-float device slots for the tensors' max |x| (fp16-pair arithmetic).  A slot is handed out once and never reused: it has to be zero
+    before the producing launch, and the zeros come from one fill per 4096 slots, stream-ordered before every launch that follows on that stream."""
+
+    def __init__(self):
+        self.pools = {}
+
+    def take(self, device) -> torch.Tensor:
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        pool = self.pools.get(key)
+        if pool is None or pool[1] >= pool[0].numel():
+            pool = self.pools[key] = [torch.zeros(4096, dtype=torch.float32, device=device), 0]
+        slot = pool[0][pool[1]:pool[1] + 1]
+        pool[1] += 1
+        return slot
+
+    def fresh(self, device):
+        """Drop the current stream's pool: the next slot comes from a new zero fill (graph capture: the fill must be part of the graph)."""
+        self.pools.pop((device, torch.cuda.current_stream(device).cuda_stream), None)
+
+
+AMAX = _AmaxSlots()
+amax_fallbacks = 0      # how many inputs needed their own ndet_amax_f32 pass (diagnostic: the hot path should carry the attribute)
+
+
+def carry_amax(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """``dst`` is a view / permutation of ``src`` (same elements): it inherits the max |x| slot."""
+    slot = getattr(src, "_ndet_amax", None)
+    if slot is not None:
+        dst._ndet_amax = slot
+    return dst
+
+
+def amax_of(x: torch.Tensor) -> torch.Tensor:
+    """The device slot holding max |x| of ``x``: left by the kernel that wrote it, or computed here in one pass."""
+    global amax_fallbacks
+    slot = getattr(x, "_ndet_amax", None)
+    if slot is None:
+        amax_fallbacks += 1
+        slot = AMAX.take(x.device)
+        st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        check(_lib.load().ndet_amax_f32(_ptr(x), x.numel(), _ptr(slot), st), "amax_f32")
+        x._ndet_amax = slot
+    return slot
 
 
 launch_hook = None  # bench.py: callable(flops, thunk, kernel_name) wrapping every MFMA-conv launch (event timing); None = direct
@@ -41,6 +100,7 @@ KERNEL_NAMES = {("bf16x3", 64): "k_conv_split<64,64,2,2>", ("bf16x3", 128): "k_c
                 ("f32", 64): "k_conv3d_igemm<64,64,2,2>", ("f32", 128): "k_conv3d_igemm<128,128,4,2>"}
 KERNEL_NAMES.update({("bf16x3", 100000 + t if t != 12864 else 112864): KERNEL_NAMES[("bf16x3", t)] for t in (64, 128, 12864)})   # direct-epilogue forms
 KERNEL_NAMES.update({("bf16", t): n for (a, t), n in list(KERNEL_NAMES.items()) if a == "bf16x3"})
+KERNEL_NAMES.update({("f16x2", t): n + "/f16x2" for (a, t), n in list(KERNEL_NAMES.items()) if a == "bf16x3"})
 
 
 def _launch(flops, thunk, arith="f32", tile=0, nbytes=0):
@@ -81,7 +141,7 @@ def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: 
     bf16x3 kernel."""
     if tile == 0 and splits in (0, 1):     # splits == 1: the caller cannot split K (transposed, upsampled residual): the table's tile, unsplit
         key = (m, cout, k_iters, int(transposed))
-        hit = (TUNED_BF16.get(key) if ARITHMETIC == "bf16" else None) or TUNED_SPLIT.get(key)
+        hit = (TUNED_BF16.get(key) if ARITHMETIC == "bf16" else TUNED_F16.get(key) if ARITHMETIC == "f16x2" else None) or TUNED_SPLIT.get(key)
         if hit is not None:
             return hit if splits == 0 else (hit[0], 1)
     if tile == 0:   # shapes outside the measured table: the pattern the sweeps showed
@@ -128,6 +188,33 @@ def split_planes(pk: dict) -> torch.Tensor:
     return planes
 
 
+def split_planes_f16(pk: dict):
+    """(planes, 1 / scale): the packed weight times a power of two that puts max |w| in [2^14, 2^15), as two fp16 planes tiled per 32-channel K
+    step, (taps, Cin/32, 2, Cout, 32) (built once per pack; reading max |w| back is the one host synchronisation, at pack time)."""
+    hit = pk.get("w_f16")
+    if hit is None:
+        w = pk["w"]
+        taps, cout, cin = w.shape
+        if cin % 32:
+            raise ValueError(f"conv_ndhwc_arith: Cin={cin} must be a multiple of 32")
+        wmax = float(w.abs().max())
+        e = math.frexp(wmax)[1] if (wmax > 0.0 and math.isfinite(wmax)) else 15
+        e = max(e, -96)
+        scale = math.ldexp(1.0, 15 - e)
+        planes = torch.empty((taps, cin // 32, 2, cout, 32), dtype=torch.int16, device=w.device)
+        st = c_void_p(torch.cuda.current_stream(w.device).cuda_stream)
+        check(_lib.load().ndet_split_weights_f16x2(_ptr(w), taps, cout, cin, scale, _ptr(planes), st), "split_weights_f16x2")
+        hit = pk["w_f16"] = (planes, 1.0 / scale)
+    return hit
+
+
+def layer_arithmetic(k_iters: int) -> str:
+    """The arithmetic one split-family launch runs in under the current mode."""
+    if ARITHMETIC == "f16x2" and k_iters < F16_MIN_KSTEPS:
+        return "bf16x3"
+    return ARITHMETIC
+
+
 def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, residual_up2, relu, splits, tile, m, k_iters, flops):
     halo_ok = (not transposed and all(s == 1 for s in stride) and all(k % 2 == 1 and q == k // 2 for k, q in zip(kernel, pad))
                and kernel[0] * kernel[1] * kernel[2] > 1)
@@ -147,13 +234,30 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
     i3 = lambda v: (ctypes.c_int * 3)(*v)
     st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     lib = _lib.load()
-    planes = split_planes(pk)
     d, h, w = dims
     nbytes = 4 * (x.numel() + pk["w"].numel() + out.numel() + (0 if residual is None else residual.numel()))
-    fn = lib.ndet_conv_ndhwc_bf16 if ARITHMETIC == "bf16" else lib.ndet_conv_ndhwc_split
-    _launch(flops, lambda: check(fn(_ptr(x), _ptr(planes), _ptr(out), d, h, w, pk["cin"], pk["cout"], i3(kernel), i3(stride), i3(pad), int(transposed),
-                                    _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), int(residual_up2), relu, splits, tile, _ptr(ws), st),
-                                 "conv_ndhwc_split"), ARITHMETIC, tile, nbytes)
+    arith = layer_arithmetic(k_iters)
+    if ARITHMETIC == "f16x2" and pk.get("arith"):
+        arith = pk["arith"]            # training packs (conv_train.py) keep their bf16x3 planes: the weights change every step
+    if ARITHMETIC != "f16x2":
+        planes = split_planes(pk)
+        fn = lib.ndet_conv_ndhwc_bf16 if arith == "bf16" else lib.ndet_conv_ndhwc_split
+        _launch(flops, lambda: check(fn(_ptr(x), _ptr(planes), _ptr(out), d, h, w, pk["cin"], pk["cout"], i3(kernel), i3(stride), i3(pad), int(transposed),
+                                        _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), int(residual_up2), relu, splits, tile, _ptr(ws), st),
+                                     "conv_ndhwc_split"), arith, tile, nbytes)
+        return out
+    # fp16-pair mode: every launch leaves max |out| behind; the fp16-pair launches read their input's
+    if arith == "f16x2":
+        planes, winv = split_planes_f16(pk)
+        in_amax = amax_of(x)
+    else:
+        planes, winv, in_amax = split_planes(pk), 1.0, None
+    out_amax = AMAX.take(x.device)
+    _launch(flops, lambda: check(lib.ndet_conv_ndhwc_arith(_ptr(x), _ptr(planes), _ptr(out), d, h, w, pk["cin"], pk["cout"], i3(kernel), i3(stride), i3(pad),
+                                                           int(transposed), _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), int(residual_up2), relu,
+                                                           splits, tile, 1 if arith == "f16x2" else 0, _ptr(in_amax), winv, _ptr(out_amax), _ptr(ws), st),
+                                 "conv_ndhwc_arith"), arith, tile, nbytes)
+    out._ndet_amax = out_amax
     return out
 
 
@@ -250,7 +354,8 @@ def packed_linear(lin: nn.Linear, pad_in_to: int = 0):
 def linear_rows(x: torch.Tensor, pk: dict, relu: int = 0) -> torch.Tensor:
     """(M, Cin) rows -> (M, Cout): a Linear (+ ReLU) as one launch of the MFMA kernel (bias and ReLU in the epilogue)."""
     assert x.dim() == 2 and x.is_contiguous()
-    return conv2d_nhwc(x.view(1, 1, x.shape[0], x.shape[1]), pk, relu=relu).view(x.shape[0], -1)
+    y = conv2d_nhwc(carry_amax(x, x.view(1, 1, x.shape[0], x.shape[1])), pk, relu=relu)
+    return carry_amax(y, y.view(x.shape[0], -1))
 
 
 def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = None, relu: int = 0, splits: int = 0, tile: int = 0):
@@ -265,7 +370,7 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
         od, oh, ow = 2 * d, 2 * h, 2 * w
     else:
         pad = int(pk["pads"][0]) if "pads" in pk else k // 2
-        assert pad == k // 2 or ARITHMETIC in ("bf16x3", "bf16"), "the fp32-MFMA family pads by k // 2"
+        assert pad == k // 2 or ARITHMETIC in SPLIT_FAMILY, "the fp32-MFMA family pads by k // 2"
         od, oh, ow = ((v + 2 * pad - k) // s + 1 for v in (d, h, w))
     out = torch.empty((od, oh, ow, cout), dtype=torch.float32, device=x.device)
     if residual is not None:
@@ -273,7 +378,7 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
     lib = _lib.load()
     m = d * h * w if tr else od * oh * ow
     flops = 2 * m * cout * cin * (1 if tr else k ** 3) * (8 if tr else 1)
-    if ARITHMETIC in ("bf16x3", "bf16"):
+    if ARITHMETIC in SPLIT_FAMILY:
         kk, ss, pp = ((2, 2, 2), (2, 2, 2), (0, 0, 0)) if tr else ((k,) * 3, (s,) * 3, (pad,) * 3)
         return _conv_split(x, pk, out, (d, h, w), kk, ss, pp, tr, residual, False, relu, splits, tile, m,
                            (cin // 32) * (1 if tr else k ** 3), flops)
@@ -309,7 +414,7 @@ def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = No
         if residual_up2:
             splits = 1
     m = n * oh * ow
-    if ARITHMETIC in ("bf16x3", "bf16"):
+    if ARITHMETIC in SPLIT_FAMILY:
         return _conv_split(x, pk, out, (n, h, w), (1, kh, kw), (1, sh, sw), (0, ph, pw), False, residual, residual_up2, relu, splits, tile, m,
                            kh * kw * (cin // 32), 2 * m * cout * cin * kh * kw)
     tile, splits = choose_tiling(m, cout, kh * kw * (cin // 32), tile, splits)
@@ -330,7 +435,7 @@ CHAIN_BOTTLENECKS = True    # conv2 -> conv3 of the 64- / 128-channel bottleneck
 def chain_ok(pk: dict, pk3: dict) -> bool:
     """The chained kernel holds ALL output channels of the first convolution in one 128 x 64 / 128 x 128 tile and multiplies them by a
     1x1 layer: a 2D convolution to 64 / 128 channels followed by a stride-1 1x1 layer to a multiple of 64, in the bf16 family."""
-    return (CHAIN_BOTTLENECKS and ARITHMETIC in ("bf16x3", "bf16") and pk["ndim"] == 2 and pk3["ndim"] == 2 and pk["cout"] in (64, 128)
+    return (CHAIN_BOTTLENECKS and ARITHMETIC in SPLIT_FAMILY and pk["ndim"] == 2 and pk3["ndim"] == 2 and pk["cout"] in (64, 128)
             and not pk["transposed"] and tuple(pk3["kernel"]) == (1, 1) and tuple(pk3["strides"]) == (1, 1) and pk3["cin"] == pk["cout"]
             and pk3["cout"] % 64 == 0 and pk["cin"] % 32 == 0 and pk["scale"] is not None and pk3["scale"] is not None)
 
@@ -352,13 +457,22 @@ def conv2d_chain_nhwc(x: torch.Tensor, pk: dict, pk3: dict, residual: Optional[t
     i3 = lambda a, b, c: (ctypes.c_int * 3)(a, b, c)
     st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     lib = _lib.load()
-    p1, p3 = split_planes(pk), split_planes(pk3)
     flops = 2 * m * mid * (cin * kh * kw + cout)
     nbytes = 4 * (x.numel() + pk["w"].numel() + pk3["w"].numel() + out.numel() + (0 if residual is None else residual.numel()))
     name = f"k_conv_split_chain<{mid}>"
-    thunk = lambda: check(lib.ndet_conv_chain_split(_ptr(x), _ptr(p1), n, h, w, cin, mid, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw), _ptr(pk["scale"]),
-                                                    _ptr(pk["shift"]), _ptr(p3), cout, _ptr(pk3["scale"]), _ptr(pk3["shift"]), _ptr(residual), relu,
-                                                    _ptr(out), 0 if ARITHMETIC == "bf16" else 2, st), "conv_chain_split")
+    if ARITHMETIC == "f16x2":
+        (p1, w1inv), (p3, w3inv) = split_planes_f16(pk), split_planes_f16(pk3)
+        in_amax, out_amax = amax_of(x), AMAX.take(x.device)
+        name += "/f16x2"
+        thunk = lambda: check(lib.ndet_conv_chain_arith(_ptr(x), _ptr(p1), n, h, w, cin, mid, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw), _ptr(pk["scale"]),
+                                                        _ptr(pk["shift"]), _ptr(p3), cout, _ptr(pk3["scale"]), _ptr(pk3["shift"]), _ptr(residual), relu,
+                                                        _ptr(out), 1, _ptr(in_amax), w1inv, w3inv, _ptr(out_amax), st), "conv_chain_arith")
+        out._ndet_amax = out_amax
+    else:
+        p1, p3 = split_planes(pk), split_planes(pk3)
+        thunk = lambda: check(lib.ndet_conv_chain_split(_ptr(x), _ptr(p1), n, h, w, cin, mid, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw), _ptr(pk["scale"]),
+                                                        _ptr(pk["shift"]), _ptr(p3), cout, _ptr(pk3["scale"]), _ptr(pk3["shift"]), _ptr(residual), relu,
+                                                        _ptr(out), 0 if ARITHMETIC == "bf16" else 2, st), "conv_chain_split")
     if launch_hook is not None:
         launch_hook(flops, thunk, name)
     else:
@@ -380,7 +494,7 @@ def bn_relu_maxpool_nhwc(x: torch.Tensor, bn: nn.BatchNorm2d) -> torch.Tensor:
 def stem_ok(conv: nn.Module, bn: nn.Module, x: torch.Tensor) -> bool:
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and isinstance(conv, nn.Conv2d) and conv.in_channels == 3 and conv.out_channels == 64
             and tuple(conv.kernel_size) == (7, 7) and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (3, 3) and conv.bias is None
-            and not bn.training and ARITHMETIC == "bf16x3" and min(x.shape[2:]) >= 7)
+            and not bn.training and ARITHMETIC in ("bf16x3", "f16x2") and min(x.shape[2:]) >= 7)
 
 
 def stem_conv_bn_relu_maxpool(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d) -> torch.Tensor:
@@ -410,4 +524,4 @@ def stem_conv_bn_relu_maxpool(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm
 def to_ndhwc(x: torch.Tensor) -> torch.Tensor:
     """logical (C,X,Y,Z) -> contiguous (X,Y,Z,C) (free when the memory already is channels-last)."""
     y = x.permute(1, 2, 3, 0)
-    return y if y.is_contiguous() else y.contiguous()
+    return carry_amax(x, y if y.is_contiguous() else y.contiguous())

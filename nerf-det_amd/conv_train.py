@@ -32,7 +32,7 @@ def _raw_pack(w_taps_co_ci: Tensor, kernel: Sequence[int], stride: int = 1, pads
     ndim = len(k)
     return dict(w=w_taps_co_ci.contiguous().float(), scale=None, shift=None, cout=int(w_taps_co_ci.shape[1]), cin=int(w_taps_co_ci.shape[2]),
                 ksize=k[0], stride=stride, transposed=False, kernel=k, strides=(stride,) * ndim,
-                pads=tuple(v // 2 for v in k) if pads is None else tuple(pads), ndim=ndim)
+                pads=tuple(v // 2 for v in k) if pads is None else tuple(pads), ndim=ndim, arith="bf16x3")
 
 
 def _train_pack(w: Tensor, kernel, adjoint: bool, stride: int = 1, pads=None) -> dict:
@@ -43,7 +43,7 @@ def _train_pack(w: Tensor, kernel, adjoint: bool, stride: int = 1, pads=None) ->
     taps = 1
     for v in kernel:
         taps *= int(v)
-    if C.ARITHMETIC not in ("bf16x3", "bf16"):
+    if C.train_arithmetic() not in ("bf16x3", "bf16"):
         if not adjoint:
             return _raw_pack(C.pack_weight(w), kernel, stride, pads)
         flip = w.flip(tuple(range(2, w.dim()))).transpose(0, 1)
@@ -59,7 +59,7 @@ def _train_pack(w: Tensor, kernel, adjoint: bool, stride: int = 1, pads=None) ->
                                                            c_void_p(torch.cuda.current_stream(w.device).cuda_stream)), "split_weights_torch")
     k = tuple(int(v) for v in kernel)
     return dict(w=wc, w_split=planes, scale=None, shift=None, cout=no, cin=ki, ksize=k[0], stride=stride, transposed=False, kernel=k,
-                strides=(stride,) * len(k), pads=tuple(v // 2 for v in k) if pads is None else tuple(pads), ndim=len(k))
+                strides=(stride,) * len(k), pads=tuple(v // 2 for v in k) if pads is None else tuple(pads), ndim=len(k), arith="bf16x3")
 
 
 def _conv(x: Tensor, pk: dict) -> Tensor:
@@ -111,7 +111,7 @@ def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pa
     lrow = ((lo + 31) // 32) * 32                           # the kernel steps the contraction by 32; the tail is staged as zeros
     taps = k3[0] * k3[1] * k3[2]
     # dy as the GEMM's "weight" operand (Cout rows over the output grid), split into bf16 planes once
-    if FUSED_DY_PLANES and C.ARITHMETIC in ("bf16x3", "bf16"):
+    if FUSED_DY_PLANES and C.train_arithmetic() in ("bf16x3", "bf16"):
         from ctypes import c_void_p
         from . import _lib
         planes = torch.empty((1, lrow // 32, 3, cout, 32), dtype=torch.int16, device=x.device)     # one pass: transpose + split
@@ -125,7 +125,7 @@ def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pa
                   pads=(0, 0), ndim=2)
     if implicit is None:
         implicit = IMPLICIT_WGRAD and taps >= 9 and lo >= 16384
-    if implicit and C.ARITHMETIC in ("bf16x3", "bf16") and cin % 64 == 0:
+    if implicit and C.train_arithmetic() in ("bf16x3", "bf16") and cin % 64 == 0:
         # multi-tap layers on large grids: x read in place (csrc/conv_split_kernels.hip::k_wgrad_split), no tap copies -- there the staged
         # form writes and re-reads taps x the input (707 MB for a 3x3x3 layer at 40x40x16x256); on small grids and 1x1 layers the staged
         # GEMM runs on the faster tiles and wins (tools/bench_wgrad.py)
@@ -143,7 +143,7 @@ def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pa
         i3 = lambda v: (ctypes.c_int * 3)(*v)
         st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(_lib.load().ndet_wgrad_split(c_void_p(x.data_ptr()), d, h, w, cin, i3(k3), i3(s3), i3(pads), c_void_p(planes.data_ptr()), cout, lrow,
-                                                splits, 0 if C.ARITHMETIC == "bf16" else 2, c_void_p(0 if ws is None else ws.data_ptr()),
+                                                splits, 0 if C.train_arithmetic() == "bf16" else 2, c_void_p(0 if ws is None else ws.data_ptr()),
                                                 c_void_p(dw.data_ptr()), st), "wgrad_split")
         return dw.view(taps, cin, cout).permute(2, 1, 0).reshape(cout, cin, *kernel)
     per = max(1, min(taps, (1 << 30) // (cin * lrow * 4)))  # the kernel addresses its operand with 32-bit byte offsets: <= 1 GiB per launch
@@ -277,7 +277,7 @@ class ConvT2(torch.autograd.Function):
         xc = x.detach().contiguous()                            # the backward kernels index it densely
         ctx.save_for_backward(xc, w)
         pk = dict(w=C.pack_weight(w, True), scale=None, shift=None, cout=int(w.shape[1]), cin=int(w.shape[0]), ksize=2, stride=2, transposed=True,
-                  kernel=(2, 2, 2), strides=(2, 2, 2), pads=(0, 0, 0), ndim=3)
+                  kernel=(2, 2, 2), strides=(2, 2, 2), pads=(0, 0, 0), ndim=3, arith="bf16x3")
         return C.conv3d_ndhwc(xc, pk)
 
     @staticmethod
@@ -293,7 +293,7 @@ class ConvT2(torch.autograd.Function):
 
 
 def eligible_transposed(conv: nn.Module, x: Tensor) -> bool:
-    return (isinstance(conv, nn.ConvTranspose3d) and C.ARITHMETIC in ("bf16x3", "bf16") and x.is_cuda and x.dtype == torch.float32 and tuple(conv.kernel_size) == (2, 2, 2)
+    return (isinstance(conv, nn.ConvTranspose3d) and C.train_arithmetic() in ("bf16x3", "bf16") and x.is_cuda and x.dtype == torch.float32 and tuple(conv.kernel_size) == (2, 2, 2)
             and tuple(conv.stride) == (2, 2, 2) and tuple(conv.padding) == (0, 0, 0) and tuple(conv.output_padding) == (0, 0, 0)
             and tuple(conv.dilation) == (1, 1, 1) and conv.groups == 1 and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0)
 

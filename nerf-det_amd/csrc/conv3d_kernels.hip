@@ -196,12 +196,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void k_co
 // fixed-order reduction of the split-K partials + epilogue
 __global__ __launch_bounds__(256) void k_conv3d_splitk_reduce(const float* __restrict__ partial, int splits, int64_t MN, int Cout,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
-                                                              const float* __restrict__ res, int relu, float* __restrict__ out) {
+                                                              const float* __restrict__ res, int relu, float* __restrict__ out,
+                                                              float* __restrict__ amax_out) {
     // VEC = 4 when Cout % 4 == 0 (host picks the grid accordingly): one float4 per thread
     const bool vec = (Cout & 3) == 0;
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * (vec ? 4 : 1);
-    if (i >= MN) return;
-    if (vec) {
+    float mx = 0.0f;
+    if (i >= MN) {
+    } else if (vec) {
         float4 v = *reinterpret_cast<const float4*>(partial + i);
         for (int s = 1; s < splits; ++s) {
             const float4 t = *reinterpret_cast<const float4*>(partial + (int64_t)s * MN + i);
@@ -219,16 +221,19 @@ __global__ __launch_bounds__(256) void k_conv3d_splitk_reduce(const float* __res
         }
         if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *reinterpret_cast<float4*>(out + i) = v;
-        return;
+        mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    } else {
+        float v = partial[i];
+        for (int s = 1; s < splits; ++s) v = v + partial[(int64_t)s * MN + i];
+        const int co = (int)(i % Cout);
+        if (scale) v = v * scale[co] + shift[co];
+        if (relu == 2) v = fmaxf(v, 0.0f);
+        if (res) v = v + res[i];
+        if (relu == 1) v = fmaxf(v, 0.0f);
+        out[i] = v;
+        mx = fabsf(v);
     }
-    float v = partial[i];
-    for (int s = 1; s < splits; ++s) v = v + partial[(int64_t)s * MN + i];
-    const int co = (int)(i % Cout);
-    if (scale) v = v * scale[co] + shift[co];
-    if (relu == 2) v = fmaxf(v, 0.0f);
-    if (res) v = v + res[i];
-    if (relu == 1) v = fmaxf(v, 0.0f);
-    out[i] = v;
+    if (amax_out) conv_amax_commit(amax_out, mx);
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -268,7 +273,7 @@ int conv_splitk_reduce_launch(const Conv3dParams& p, hipStream_t st, const char*
     const int64_t mn = (int64_t)p.M * p.Cout;
     const int64_t work = (p.Cout & 3) == 0 ? mn / 4 : mn;
     hipLaunchKernelGGL(k_conv3d_splitk_reduce, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, p.partial, p.splits, mn, p.Cout, p.scale,
-                       p.shift, p.res, p.relu, p.out);
+                       p.shift, p.res, p.relu, p.out, p.amax_out);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }

@@ -31,9 +31,39 @@ struct Conv3dParams {
     int order = 0;        // bf16x3 grid kernels: which workgroups meet in one XCD's L2 (workgroup b is dispatched to XCD b % 8).  0: grid order (row tiles
                           // fastest).  1: the row tiles of one (column tile, K split) weight slice run on one XCD -- layers whose weights outweigh their
                           // activations (the 20x20x8 / 10x10x4 neck levels: 42 - 170 MB of weight planes, re-streamed from HBM by every XCD in grid order)
-    float xscale;         // fp16-pair tiles: power of two the activations are multiplied by while they are split (its inverse, and the
-                          // weight scale's, are folded into `scale` by the caller)
+    // fp16-pair arithmetic (max_order == 1; conv_split_kernels.hip, SCH 1): both operands are pre-scaled by a power of two so that their largest
+    // magnitude sits in [2^14, 2^15) -- the weights once, when their planes are built (`winv` = 1 / that scale), the activations while
+    // they are split, by the scale the kernel derives from `amax_in`; the epilogue multiplies the accumulators by the inverse of both.
+    const float* amax_in = nullptr;   // device: max |in| over the whole input tensor (any upper bound within ~2^10 of it serves)
+    float winv = 1.0f;                // 1 / (weight scale)
+    float* amax_out = nullptr;        // any arithmetic, optional: max |out| is atomically maxed into *amax_out (as uint bits: the slot must be zeroed
+                                      // by the caller before the launch) -- the next layer's amax_in without another pass over the tensor
 };
+
+// Power-of-two activation scale of the fp16-pair kernels and its inverse, from the tensor's max |x| = m 2^(eb-126), m in [1/2, 1):
+// x * conv_xscale < 2^15.  Tensors whose maximum is below 2^-97 (eb < 30) are scaled by 2^111: no overflow of the scale itself.
+__device__ __forceinline__ float conv_xscale_of(float amax) {
+    int eb = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    eb = eb < 30 ? 30 : eb;
+    return __uint_as_float((unsigned)(268 - eb) << 23);
+}
+__device__ __forceinline__ float conv_xinv_of(float amax) {
+    int eb = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    eb = eb < 30 ? 30 : eb;
+    return __uint_as_float((unsigned)(eb - 14) << 23);
+}
+__device__ __forceinline__ float conv_xscale(const float* amax) { return conv_xscale_of(*amax); }
+__device__ __forceinline__ float conv_xinv(const float* amax) { return conv_xinv_of(*amax); }
+// what the accumulators are multiplied by before the epilogue's affine: 1 except in the fp16-pair arithmetic (exact: a power of two)
+__device__ __forceinline__ float conv_oscale(const Conv3dParams& p) { return p.amax_in ? conv_xinv(p.amax_in) * p.winv : 1.0f; }
+
+// max |v| of a wave -> one atomic on the layer's amax slot (non-negative floats order like their bit patterns).  Every lane of the
+// wave must arrive.
+__device__ __forceinline__ void conv_amax_commit(float* slot, float mx) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(mx));
+}
 
 // internal launchers (one per kernel family) and the shared split-K reduction
 int conv_f32_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn);
@@ -74,6 +104,8 @@ __device__ __forceinline__ void conv_store_rows_mapped(const Conv3dParams& p, co
                                                        int zsplit, RowMap m_of) {
     const bool raw = (!p.transposed && p.splits > 1);
     float* dst = raw ? p.partial + (int64_t)zsplit * p.M * p.Cout : p.out;
+    const float osc = conv_oscale(p);
+    float mx = 0.0f;
     auto res_row = [&](int m, int64_t orow) -> int64_t {
         if (!p.res_up2) return orow;
         const int ow = m % p.OW, oh = (m / p.OW) % p.OH, od = m / (p.OW * p.OH);
@@ -87,6 +119,7 @@ __device__ __forceinline__ void conv_store_rows_mapped(const Conv3dParams& p, co
             if (m < 0 || m >= p.M || co >= p.Cout) continue;
             const int64_t orow = conv_out_row(p, m, ztap);
             float4 v = *reinterpret_cast<const float4*>(Cs + row * cld + c4 * 4);
+            v.x *= osc; v.y *= osc; v.z *= osc; v.w *= osc;
             if (!raw) {
                 if (p.scale) {
                     const float4 sc = *reinterpret_cast<const float4*>(p.scale + co), sh = *reinterpret_cast<const float4*>(p.shift + co);
@@ -98,6 +131,7 @@ __device__ __forceinline__ void conv_store_rows_mapped(const Conv3dParams& p, co
                     v.x = v.x + rr.x; v.y = v.y + rr.y; v.z = v.z + rr.z; v.w = v.w + rr.w;
                 }
                 if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             }
             *reinterpret_cast<float4*>(dst + orow * p.Cout + co) = v;
         }
@@ -107,16 +141,18 @@ __device__ __forceinline__ void conv_store_rows_mapped(const Conv3dParams& p, co
             const int m = m_of(row), co = n0 + c;
             if (m < 0 || m >= p.M || co >= p.Cout) continue;
             const int64_t orow = conv_out_row(p, m, ztap);
-            float v = Cs[row * cld + c];
+            float v = Cs[row * cld + c] * osc;
             if (!raw) {
                 if (p.scale) v = v * p.scale[co] + p.shift[co];
                 if (p.relu == 2) v = fmaxf(v, 0.0f);
                 if (p.res) v = v + p.res[res_row(m, orow) * p.Cout + co];
                 if (p.relu == 1) v = fmaxf(v, 0.0f);
+                mx = fmaxf(mx, fabsf(v));
             }
             dst[orow * p.Cout + co] = v;
         }
     }
+    if (p.amax_out && !raw) conv_amax_commit(p.amax_out, mx);   // (split-K: the reduce pass sees the final values)
 }
 
 // tile rows are consecutive GEMM rows starting at m_first

@@ -81,10 +81,51 @@ __device__ __forceinline__ void spl_split4_f16(const float4 v, float scale, uint
     p1 = make_uint2(o1[0], o1[1]);
 }
 
-// ONE: the leading bf16 plane only, one product per multiply (bf16 autocast arithmetic).
+// Arithmetic scheme of a kernel instantiation.  SCH 0: three bf16 planes, six products (fp32-class to 2^-24).  SCH 1: two fp16 planes of the
+// pre-scaled operands, three products (spl_split4_f16).  SCH 2: the leading bf16 plane only, one product (bf16 autocast arithmetic; the
+// weight tensor keeps its three-plane layout).
+template <int SCH> struct Spl {
+    static constexpr int NPL = SCH == 1 ? 2 : (SCH == 2 ? 1 : 3);   // operand planes staged and multiplied
+    static constexpr int WPL = SCH == 1 ? 2 : 3;                    // planes per K step in the weight tensor
+};
+template <int SCH>
+__device__ __forceinline__ void spl_split(const float4 v, float xs, uint2& s0, uint2& s1, uint2& s2) {
+    if (SCH == 1) spl_split4_f16(v, xs, s0, s1);
+    else if (SCH == 2) s0 = make_uint2(spl_pack(v.x, v.y), spl_pack(v.z, v.w));
+    else spl_split4(v, s0, s1, s2);
+}
+// two values -> the scheme's planes, packed pairs (element 0 in the low half)
+template <int SCH>
+__device__ __forceinline__ void spl_split2(float a, float b, float xs, uint32_t& o0, uint32_t& o1, uint32_t& o2) {
+    if (SCH == 1) {
+        a *= xs; b *= xs;
+        o0 = spl_pack_f16(a, b);
+        o1 = spl_pack_f16(a - spl_f16_lo(o0), b - spl_f16_hi(o0));
+    } else {
+        o0 = spl_pack(a, b);
+        if (SCH == 0) {
+            const float ra = a - spl_lo(o0), rb = b - spl_hi(o0);
+            o1 = spl_pack(ra, rb);
+            o2 = spl_pack(ra - spl_lo(o1), rb - spl_hi(o1));
+        }
+    }
+}
+typedef float f32x16_ __attribute__((ext_vector_type(16)));
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+template <int SCH>
+__device__ __forceinline__ f32x16_ spl_mfma32(bf16x8 a, bf16x8 b, f32x16_ c) {
+    if (SCH == 1) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <int SCH>
+__device__ __forceinline__ f32x4_ spl_mfma16(bf16x8 a, bf16x8 b, f32x4_ c) {
+    if (SCH == 1) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // K walk of the unified tiles: fills acc (per-wave 32x32 MFMA tiles) for GEMM rows m0.. and channels n0..; returns the transposed-conv tap
 // (blockIdx.z) in ztap.  Ends behind a barrier: the LDS operand planes are free for the epilogue.
-template <int BM, int BN, int WGM, int WGN, bool ONE>
+template <int BM, int BN, int WGM, int WGN, int SCH>
 __device__ __forceinline__ void conv_split_mainloop(const Conv3dParams& p, const uint16_t* __restrict__ wsplit, uint16_t* lds16,
                                                     f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int& ztap) {
     constexpr int NTHR = 64 * WGM * WGN;
@@ -95,7 +136,8 @@ __device__ __forceinline__ void conv_split_mainloop(const Conv3dParams& p, const
     constexpr int AR = BM / RPA, BR = BN / RPB;
     static_assert(AR >= 1 && BR >= 1 && MT >= 1 && NT >= 1, "tile too small for the thread count");
     constexpr int APL = BM * SPL_RS, BPL = BN * SPL_RS;  // one plane, in bf16 elements
-    constexpr int NPL = ONE ? 1 : 3;
+    constexpr int NPL = Spl<SCH>::NPL, WPL = Spl<SCH>::WPL;
+    const float xs = SCH == 1 ? conv_xscale(p.amax_in) : 1.0f;
     uint16_t* As = lds16;               // [NPL][BM][SPL_RS]
     uint16_t* Bs = lds16 + NPL * APL;   // [NPL][BN][SPL_RS]
 
@@ -176,7 +218,7 @@ __device__ __forceinline__ void conv_split_mainloop(const Conv3dParams& p, const
             const float4 v = *reinterpret_cast<const float4*>(ok ? rowbase[i] + toff : p.in + akq * 4);   // always issued
             ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const uint16_t* bt = bbase_g + ((int64_t)tap * cin_steps + ncs) * 3 * wtile;
+        const uint16_t* bt = bbase_g + ((int64_t)tap * cin_steps + ncs) * WPL * wtile;
 #pragma unroll
         for (int i = 0; i < BR; ++i)
 #pragma unroll
@@ -196,14 +238,11 @@ __device__ __forceinline__ void conv_split_mainloop(const Conv3dParams& p, const
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             uint2 s0, s1, s2;
-            if (ONE) s0 = make_uint2(spl_pack(ra[i].x, ra[i].y), spl_pack(ra[i].z, ra[i].w));
-            else spl_split4(ra[i], s0, s1, s2);
+            spl_split<SCH>(ra[i], xs, s0, s1, s2);
             uint16_t* dst = As + (arow_ + RPA * i) * SPL_RS + akq * 4;
             *reinterpret_cast<uint2*>(dst) = s0;
-            if (!ONE) {
-                *reinterpret_cast<uint2*>(dst + APL) = s1;
-                *reinterpret_cast<uint2*>(dst + 2 * APL) = s2;
-            }
+            if (NPL > 1) *reinterpret_cast<uint2*>(dst + APL) = s1;
+            if (NPL > 2) *reinterpret_cast<uint2*>(dst + 2 * APL) = s2;
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
@@ -247,7 +286,7 @@ __device__ __forceinline__ void conv_split_mainloop(const Conv3dParams& p, const
                     for (int ta = 0; ta < MT; ++ta)
 #pragma unroll
                         for (int tb = 0; tb < NT; ++tb)
-                            acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][ta], fb[pb][tb], acc[ta][tb], 0, 0, 0);
+                            acc[ta][tb] = spl_mfma32<SCH>(fa[pa][ta], fb[pb][tb], acc[ta][tb]);
                 }
         }
         __syncthreads();   // every wave is done reading this K step
@@ -256,7 +295,7 @@ __device__ __forceinline__ void conv_split_mainloop(const Conv3dParams& p, const
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool ONE = false>
+template <int BM, int BN, int WGM, int WGN, int SCH = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dParams p, const uint16_t* __restrict__ wsplit) {
     constexpr int NTHR = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
@@ -268,10 +307,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
     const int m0 = blk.x * BM, n0 = blk.y * BN;
     f32x16 acc[MT][NT];
     int ztap;
-    conv_split_mainloop<BM, BN, WGM, WGN, ONE>(p, wsplit, lds16, acc, ztap);
+    conv_split_mainloop<BM, BN, WGM, WGN, SCH>(p, wsplit, lds16, acc, ztap);
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     if (p.direct) {
+        const float osc = conv_oscale(p);
+        float mx = 0.0f;
         // ---- direct epilogue: a register of a 32 x 32 tile is 32 consecutive channels of one row = one 128-byte line; residual reads and
         // stores are buffer operations (lane part of the address in one VGPR, the register's row in the scalar offset, rows past M outside the
         // descriptor).  No LDS staging, no barrier: the workgroup's waves drain independently while the CU's other workgroups multiply ----
@@ -285,7 +326,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
             const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.scale ? p.shift[co] : 0.0f;
 #pragma unroll
             for (int ta = 0; ta < MT; ++ta) {
-                const unsigned vo = (unsigned)(((int64_t)(m0 + wm * WM + ta * 32 + 4 * (lane >> 5)) * p.Cout + co) * 4);
+                const int mrow = m0 + wm * WM + ta * 32 + 4 * (lane >> 5);
+                const unsigned vo = (unsigned)(((int64_t)mrow * p.Cout + co) * 4);
                 float rr[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -295,14 +337,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(((r & 3) + 8 * (r >> 2)) * p.Cout * 4));
-                    float v = acc[ta][tb][r] * sc + sh;
+                    float v = (acc[ta][tb][r] * osc) * sc + sh;
                     if (p.relu == 2) v = fmaxf(v, 0.f);
                     v += rr[r];
                     if (p.relu == 1) v = fmaxf(v, 0.f);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, vo, so, 0);
+                    if (mrow + (r & 3) + 8 * (r >> 2) < p.M) mx = fmaxf(mx, fabsf(v));      // rows past M: dropped stores of values that are not the layer's
                 }
             }
         }
+        if (p.amax_out) conv_amax_commit(p.amax_out, mx);
         return;
     }
     // ---- epilogue: accumulators -> LDS (one wave-row of the tile at a time) -> fused row-wise stores ----
@@ -336,7 +380,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
 // whole 128-byte line for the residual read and the store.
 // ------------------------------------------------------------------------------------------------
 struct ConvChain {
-    const uint16_t* w3;    // (1, MID/32, 3, Cout3, 32) bf16 planes
+    const uint16_t* w3;    // (1, MID/32, 3, Cout3, 32) bf16 planes  [fp16 pair: (1, MID/32, 2, Cout3, 32), pre-scaled by 1 / w3inv]
+    float w3inv;           // fp16 pair: 1 / (scale of w3)
+    float* amax_out;       // optional: max |out| (see Conv3dParams::amax_out)
     const float* scale3;   // (Cout3) or null
     const float* shift3;
     const float* res;      // (M, Cout3) or null
@@ -345,11 +391,11 @@ struct ConvChain {
     int relu3;             // 0 none, 1 ReLU last, 2 ReLU before the residual add
 };
 
-template <int MID, bool ONE>
+template <int MID, int SCH>
 __global__ __launch_bounds__(256, MID == 64 ? 3 : 2) void k_conv_split_chain(const Conv3dParams p, const uint16_t* __restrict__ wsplit, const ConvChain c) {
     constexpr int BM = 128, BN = MID, WGM = 2, WGN = 2;
     constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
-    constexpr int NPL = ONE ? 1 : 3;
+    constexpr int NPL = Spl<SCH>::NPL, WPL = Spl<SCH>::WPL;
     constexpr int YRS = MID;              // LDS rows of the intermediate are unpadded; the 16-byte chunk index is XORed with row & 7 (fragment reads
     constexpr int HALVES = MID == 128 ? 2 : 1;   // 128 channels: the intermediate is chained 64 rows at a time (48 KB of LDS either way)
     constexpr int RH = BM / HALVES;
@@ -364,9 +410,39 @@ __global__ __launch_bounds__(256, MID == 64 ? 3 : 2) void k_conv_split_chain(con
     const int m0 = blockIdx.x * BM;
     f32x16 acc[MT][NT];
     int ztap;
-    conv_split_mainloop<BM, BN, WGM, WGN, ONE>(p, wsplit, lds16, acc, ztap);
+    conv_split_mainloop<BM, BN, WGM, WGN, SCH>(p, wsplit, lds16, acc, ztap);
 
-    // ---- intermediate: BN + ReLU, bf16 split, into LDS as the A operand of the chained GEMM ----
+    // ---- intermediate: BN + ReLU in place.  fp16 pair: its scale comes from the workgroup's own maximum (the tile is multiplied by W3 here and
+    // nowhere else, so the scale only has to be the same for the rows and K slices of this workgroup's chained GEMM) ----
+    float ys = 1.0f, osc3 = 1.0f;
+    if constexpr (SCH == 1) {
+        const float osc1 = conv_oscale(p);
+        float ymax = 0.0f;
+#pragma unroll
+        for (int ta = 0; ta < MT; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < NT; ++tb) {
+                const int col = wn * WN + tb * 32 + (lane & 31);
+                const float sc = p.scale ? p.scale[col] : 1.0f, sh = p.scale ? p.shift[col] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float a = (acc[ta][tb][r] * osc1) * sc + sh;
+                    if (p.relu) a = fmaxf(a, 0.f);
+                    acc[ta][tb][r] = a;
+                    ymax = fmaxf(ymax, fabsf(a));
+                }
+            }
+        __shared__ float wg_max[4];
+#pragma unroll
+        for (int o = 32; o; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+        if (lane == 0) wg_max[wave] = ymax;
+        __syncthreads();
+        ymax = fmaxf(fmaxf(wg_max[0], wg_max[1]), fmaxf(wg_max[2], wg_max[3]));
+        ys = conv_xscale_of(ymax);
+        osc3 = conv_xinv_of(ymax) * c.w3inv;
+    }
+    float omax = 0.0f;
+    // ---- the intermediate's split, into LDS as the A operand of the chained GEMM ----
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     uint16_t* Y = lds16;
     const int frow = lane & 31, fk = (lane >> 5) * 8;
@@ -381,23 +457,22 @@ __global__ __launch_bounds__(256, MID == 64 ? 3 : 2) void k_conv_split_chain(con
 #pragma unroll
                 for (int tb = 0; tb < NT; ++tb) {
                     const int col = wn * WN + tb * 32 + (lane & 31);
-                    const float sc = p.scale ? p.scale[col] : 1.0f, sh = p.scale ? p.shift[col] : 0.0f;
+                    const float sc = (SCH != 1 && p.scale) ? p.scale[col] : 1.0f, sh = (SCH != 1 && p.scale) ? p.shift[col] : 0.0f;
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
-                        float a = acc[ta][tb][r] * sc + sh, b = acc[ta][tb][r + 1] * sc + sh;   // rows r and r + 1 of this lane's column
-                        if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+                        float a = acc[ta][tb][r], b = acc[ta][tb][r + 1];   // rows r and r + 1 of this lane's column
+                        if (SCH != 1) {                                      // (fp16 pair: BN + ReLU were applied in place above)
+                            a = a * sc + sh; b = b * sc + sh;
+                            if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+                        }
                         const int row = (HALVES == 1 ? wm * WM : 0) + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                         uint16_t* da = Y + row * YRS + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7));
                         uint16_t* db = Y + (row + 1) * YRS + ((((col >> 3) ^ ((row + 1) & 7)) << 3) | (col & 7));
-                        const uint32_t o0 = spl_pack(a, b);
+                        uint32_t o0, o1 = 0, o2 = 0;
+                        spl_split2<SCH>(a, b, ys, o0, o1, o2);
                         da[0] = (uint16_t)o0; db[0] = (uint16_t)(o0 >> 16);
-                        if (!ONE) {
-                            const float ra = a - spl_lo(o0), rb = b - spl_hi(o0);
-                            const uint32_t o1 = spl_pack(ra, rb);
-                            da[YPL] = (uint16_t)o1; db[YPL] = (uint16_t)(o1 >> 16);
-                            const uint32_t o2 = spl_pack(ra - spl_lo(o1), rb - spl_hi(o1));
-                            da[2 * YPL] = (uint16_t)o2; db[2 * YPL] = (uint16_t)(o2 >> 16);
-                        }
+                        if (NPL > 1) { da[YPL] = (uint16_t)o1; db[YPL] = (uint16_t)(o1 >> 16); }
+                        if (NPL > 2) { da[2 * YPL] = (uint16_t)o2; db[2 * YPL] = (uint16_t)(o2 >> 16); }
                     }
                 }
         }
@@ -420,7 +495,7 @@ __global__ __launch_bounds__(256, MID == 64 ? 3 : 2) void k_conv_split_chain(con
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl) {
                         const int ks = kg * KG + k4;
-                        fb[pl][k4] = *reinterpret_cast<const bf16x8*>(c.w3 + ((int64_t)(ks >> 1) * 3 + pl) * w3pl + (int64_t)co * CBK + (ks & 1) * 16 + fk);
+                        fb[pl][k4] = *reinterpret_cast<const bf16x8*>(c.w3 + ((int64_t)(ks >> 1) * WPL + pl) * w3pl + (int64_t)co * CBK + (ks & 1) * 16 + fk);
                     }
             };
             auto mul = [&](f32x16& cc, const bf16x8 (&fb)[NPL][KG], int rt, int kg) {
@@ -435,7 +510,7 @@ __global__ __launch_bounds__(256, MID == 64 ? 3 : 2) void k_conv_split_chain(con
                     for (int order = NPL - 1; order >= 0; --order)
                         if (order <= p.max_order)
 #pragma unroll
-                            for (int pa = 0; pa <= order; ++pa) cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa], fb[order - pa][k4], cc, 0, 0, 0);
+                            for (int pa = 0; pa <= order; ++pa) cc = spl_mfma32<SCH>(fa[pa], fb[order - pa][k4], cc);
                 }
             };
             // residual reads and stores as buffer operations: the lane's part of the address is one VGPR for the whole pass, the row of
@@ -452,11 +527,12 @@ __global__ __launch_bounds__(256, MID == 64 ? 3 : 2) void k_conv_split_chain(con
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((rt * 32 + (r & 3) + 8 * (r >> 2)) * c.Cout3 * 4));
-                    float v = cc[r] * sc3 + sh3;
+                    float v = (cc[r] * osc3) * sc3 + sh3;
                     if (c.relu3 == 2) v = fmaxf(v, 0.f);
                     v += rr[r];
                     if (c.relu3 == 1) v = fmaxf(v, 0.f);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, vo, so, 0);
+                    if (m0 + h * RH + 4 * (lane >> 5) + rt * 32 + (r & 3) + 8 * (r >> 2) < p.M) omax = fmaxf(omax, fabsf(v));
                 }
             };
             if constexpr (NKG == 1) {
@@ -493,6 +569,7 @@ __global__ __launch_bounds__(256, MID == 64 ? 3 : 2) void k_conv_split_chain(con
         }
         if (h + 1 < HALVES) __syncthreads();
     }
+    if (c.amax_out) conv_amax_commit(c.amax_out, omax);
 }
 
 
@@ -719,11 +796,11 @@ __device__ __forceinline__ void spl_dma16(__amdgpu_buffer_rsrc_t rsrc, uint16_t*
 #define WS_DEPTH 2
 #define WS_OOB 0x80000000u
 
-// ONE: the leading bf16 plane only, one product per multiply (bf16 autocast arithmetic); the weight tensor keeps its three planes.
-template <bool ONE>
+// SCH: the arithmetic scheme (Spl above).
+template <int SCH>
 __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, const uint16_t* __restrict__ wsplit) {
     constexpr int APL = WS_BM * CBK, BPL = WS_BN * CBK;   // one plane, in bf16 elements
-    constexpr int NPL = ONE ? 1 : 3;
+    constexpr int NPL = Spl<SCH>::NPL, WPL = Spl<SCH>::WPL;
     constexpr int STAGE = NPL * (APL + BPL);
     constexpr int AR = 4, BR = 4;                          // rows per producer thread: A 128 / 32, B 256 / 64
     extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
@@ -800,6 +877,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
             bvoff[i] = co < p.Cout ? (unsigned)((co * CBK + ((bkg ^ ws_swz(row)) * 8)) * 2) : WS_OOB;
         }
         const int pw4 = wave - 4;
+        const float xs = SCH == 1 ? conv_xscale(p.amax_in) : 1.0f;
         const unsigned wtile_b = (unsigned)p.Cout * CBK * 2;   // bytes of one weight plane of one K step
         // LDS destinations (bytes within a stage): the chunk swizzle depends on the row only through (row >> 2) & 3
         unsigned adst[AR];
@@ -822,7 +900,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
         auto dma_b = [&](int u, bool live) {   // weight tile u -> stage u & 1 (past the end: the last tile again, into a stage nobody reads)
             if (live) {
                 const int tap = p.transposed ? ztap : (bkd * wkh + bkh) * wkw + bkw;
-                soff = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)tap * cin_steps + bcs) * 3) * wtile_b);
+                soff = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)tap * cin_steps + bcs) * WPL) * wtile_b);
             }
             uint16_t* stage = lds16 + (u & 1) * STAGE + NPL * APL;
 #pragma unroll
@@ -867,13 +945,10 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
                 const u32x4 u = ra[slot][i];
                 uint2 s0, s1, s2;
                 const float4 xv = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
-                if (ONE) s0 = make_uint2(spl_pack(xv.x, xv.y), spl_pack(xv.z, xv.w));
-                else spl_split4(xv, s0, s1, s2);
+                spl_split<SCH>(xv, xs, s0, s1, s2);
                 *reinterpret_cast<uint2*>(base + adst[i]) = s0;
-                if (!ONE) {
-                    *reinterpret_cast<uint2*>(base + adst[i] + APL * 2) = s1;
-                    *reinterpret_cast<uint2*>(base + adst[i] + APL * 4) = s2;
-                }
+                if (NPL > 1) *reinterpret_cast<uint2*>(base + adst[i] + APL * 2) = s1;
+                if (NPL > 2) *reinterpret_cast<uint2*>(base + adst[i] + APL * 4) = s2;
             }
         };
 
@@ -928,7 +1003,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
                         for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
                             for (int tb = 0; tb < 8; ++tb)
-                                acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pa][ta], fb[pb][tb], acc[ta][tb], 0, 0, 0);
+                                acc[ta][tb] = spl_mfma16<SCH>(fa[pa][ta], fb[pb][tb], acc[ta][tb]);
                     }
             }
             __syncthreads();
@@ -955,6 +1030,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
     }
 }
 
+// arithmetic scheme of a launch (Spl): max_order 2 = bf16x3, 1 = fp16 pair, 0 = one bf16 product
+static inline int conv_scheme(const Conv3dParams& p) { return p.max_order == 0 ? 2 : (p.max_order == 1 ? 1 : 0); }
+
 static int split_launch_ws(const Conv3dParams& p, hipStream_t st, const char* fn) {
     const int taps = p.transposed ? 1 : p.kd * p.kh * p.kw;
     NDET_REQUIRE(taps <= 32, NDET_E_UNSUPPORTED, "%s: the 128x256 tile supports at most 32 taps", fn);
@@ -962,19 +1040,20 @@ static int split_launch_ws(const Conv3dParams& p, hipStream_t st, const char* fn
                  NDET_E_UNSUPPORTED, "%s: the 128x256 tile addresses at most 2 GB per operand", fn);
     const int zdim = p.transposed ? 8 : p.splits;
     dim3 grid((p.M + WS_BM - 1) / WS_BM, (p.Cout + WS_BN - 1) / WS_BN, zdim);
-    const bool one = p.max_order == 0;
-    size_t lds = (size_t)2 * (one ? 1 : 3) * (WS_BM + WS_BN) * CBK * sizeof(uint16_t);
+    const int sch = conv_scheme(p);
+    size_t lds = (size_t)2 * (sch == 2 ? 1 : (sch == 1 ? 2 : 3)) * (WS_BM + WS_BN) * CBK * sizeof(uint16_t);
     const size_t cs = (size_t)64 * (WS_BN + 4) * sizeof(float);   // the epilogue's C staging
     if (cs > lds) lds = cs;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[one]) {
-        hipError_t e = one ? hipFuncSetAttribute((const void*)k_conv_split_ws<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                           : hipFuncSetAttribute((const void*)k_conv_split_ws<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool attr_set[3] = {false, false, false};
+    const void* kfn = sch == 2 ? (const void*)k_conv_split_ws<2> : (sch == 1 ? (const void*)k_conv_split_ws<1> : (const void*)k_conv_split_ws<0>);
+    if (!attr_set[sch]) {
+        hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
-        attr_set[one] = true;
+        attr_set[sch] = true;
     }
-    if (one) hipLaunchKernelGGL(k_conv_split_ws<true>, grid, dim3(512), lds, st, p, (const uint16_t*)p.w);
-    else hipLaunchKernelGGL(k_conv_split_ws<false>, grid, dim3(512), lds, st, p, (const uint16_t*)p.w);
+    if (sch == 2) hipLaunchKernelGGL(k_conv_split_ws<2>, grid, dim3(512), lds, st, p, (const uint16_t*)p.w);
+    else if (sch == 1) hipLaunchKernelGGL(k_conv_split_ws<1>, grid, dim3(512), lds, st, p, (const uint16_t*)p.w);
+    else hipLaunchKernelGGL(k_conv_split_ws<0>, grid, dim3(512), lds, st, p, (const uint16_t*)p.w);
     return NDET_OK;
 }
 
@@ -1009,13 +1088,13 @@ __device__ __forceinline__ void lds_store64_unseen(unsigned addr, uint2 v) {
 #ifndef WSP_DEPTH
 #define WSP_DEPTH 2    // K steps of activation loads in flight per producer wave
 #endif
-template <bool ONE, int BM, int NCONS>
+template <int SCH, int BM, int NCONS>
 __global__ __launch_bounds__(64 * (NCONS + 4), 1) void k_conv_split_wsp(const Conv3dParams p, const uint16_t* __restrict__ wsplit, int n_mt, int n_nt) {
     static_assert((BM == 128 && (NCONS == 4 || NCONS == 8)) || (BM == 64 && NCONS == 4), "consumer layouts: 2 x 2 of 64 x 128, 2 x 4 of 64 x 64, 1 x 4 of 64 x 64");
     constexpr int CW = NCONS / (BM / 64);                 // consumer waves along N (BM / 64 along M)
     constexpr int WNC = WS_BN / CW, NTB = WNC / 16;       // columns and 16-column MFMA tiles per consumer wave
     constexpr int APL = BM * CBK, BPL = WS_BN * CBK;      // one plane, in bf16 elements
-    constexpr int NPL = ONE ? 1 : 3;
+    constexpr int NPL = Spl<SCH>::NPL, WPL = Spl<SCH>::WPL;
     constexpr int STAGE = NPL * (APL + BPL);
     extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
 
@@ -1023,6 +1102,9 @@ __global__ __launch_bounds__(64 * (NCONS + 4), 1) void k_conv_split_wsp(const Co
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool consumer = wave < NCONS;
+    const float xs = SCH == 1 ? conv_xscale(p.amax_in) : 1.0f;
+    const float osc = conv_oscale(p);
+    float mx = 0.0f;
     const int wm = (wave % NCONS) / CW, wn = (wave % NCONS) % CW;
 
     const int cin_steps = p.Cin / CBK;
@@ -1103,7 +1185,7 @@ __global__ __launch_bounds__(64 * (NCONS + 4), 1) void k_conv_split_wsp(const Co
             auto stage_tile = [&](int u, int slot, bool live) {
                 if (live) {
                     const int tap = (bkd * wkh + bkh) * wkw + bkw;
-                    soff = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)tap * cin_steps + bcs) * 3) * wtile_b);
+                    soff = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)tap * cin_steps + bcs) * WPL) * wtile_b);
                     if (++bkw == wkw) {
                         bkw = 0;
                         if (++bkh == wkh) {
@@ -1125,13 +1207,10 @@ __global__ __launch_bounds__(64 * (NCONS + 4), 1) void k_conv_split_wsp(const Co
                     const u32x4 uu = ra[slot][i];
                     uint2 s0, s1, s2;
                     const float4 xv = make_float4(__uint_as_float(uu.x), __uint_as_float(uu.y), __uint_as_float(uu.z), __uint_as_float(uu.w));
-                    if (ONE) s0 = make_uint2(spl_pack(xv.x, xv.y), spl_pack(xv.z, xv.w));
-                    else spl_split4(xv, s0, s1, s2);
+                    spl_split<SCH>(xv, xs, s0, s1, s2);
                     lds_store64_unseen<0>(abase + adst[i], s0);
-                    if (!ONE) {
-                        lds_store64_unseen<APL * 2>(abase + adst[i], s1);
-                        lds_store64_unseen<APL * 4>(abase + adst[i], s2);
-                    }
+                    if (NPL > 1) lds_store64_unseen<APL * 2>(abase + adst[i], s1);
+                    if (NPL > 2) lds_store64_unseen<APL * 4>(abase + adst[i], s2);
                 }
             };
             auto load_tile = [&](int slot, bool live) {
@@ -1204,7 +1283,7 @@ __global__ __launch_bounds__(64 * (NCONS + 4), 1) void k_conv_split_wsp(const Co
                             for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
                                 for (int tb = 0; tb < NTB; ++tb)
-                                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pa][ta], fb[pb][tb], acc[ta][tb], 0, 0, 0);
+                                    acc[ta][tb] = spl_mfma16<SCH>(fa[pa][ta], fb[pb][tb], acc[ta][tb]);
                         }
                 }
                 __syncthreads();
@@ -1255,18 +1334,20 @@ __global__ __launch_bounds__(64 * (NCONS + 4), 1) void k_conv_split_wsp(const Co
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((16 * ta + r) * p.Cout * 4));
-                        float v = acc[ta][tb][r];
+                        float v = acc[ta][tb][r] * osc;
                         if (!raw) {
                             if (p.scale) v = v * sc + sh;
                             if (p.relu == 2) v = fmaxf(v, 0.f);
                             if (has_res) v = v + rr[ta][r];
                             if (p.relu == 1) v = fmaxf(v, 0.f);
+                            if (rowl + 16 * ta + r < p.M) mx = fmaxf(mx, fabsf(v));
                         }
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, vo, so, 0);
                     }
             }
         }
     }
+    if (p.amax_out && p.splits == 1) conv_amax_commit(p.amax_out, mx);
 }
 
 template <int BM, int NCONS>
@@ -1288,17 +1369,18 @@ static int split_launch_wsp(const Conv3dParams& p, hipStream_t st, const char* f
         else n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int grid = (int)(n_tiles < n_cu ? n_tiles : n_cu);
-    const bool one = p.max_order == 0;
-    const size_t lds = (size_t)2 * (one ? 1 : 3) * (BM + WS_BN) * CBK * sizeof(uint16_t);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[one]) {
-        hipError_t e = one ? hipFuncSetAttribute((const void*)k_conv_split_wsp<true, BM, NCONS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                           : hipFuncSetAttribute((const void*)k_conv_split_wsp<false, BM, NCONS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int sch = conv_scheme(p);
+    const size_t lds = (size_t)2 * (sch == 2 ? 1 : (sch == 1 ? 2 : 3)) * (BM + WS_BN) * CBK * sizeof(uint16_t);
+    static bool attr_set[3] = {false, false, false};
+    const void* kfn = sch == 2 ? (const void*)k_conv_split_wsp<2, BM, NCONS> : (sch == 1 ? (const void*)k_conv_split_wsp<1, BM, NCONS> : (const void*)k_conv_split_wsp<0, BM, NCONS>);
+    if (!attr_set[sch]) {
+        hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
-        attr_set[one] = true;
+        attr_set[sch] = true;
     }
-    if (one) hipLaunchKernelGGL((k_conv_split_wsp<true, BM, NCONS>), dim3(grid), dim3(64 * (NCONS + 4)), lds, st, p, (const uint16_t*)p.w, n_mt, n_nt);
-    else hipLaunchKernelGGL((k_conv_split_wsp<false, BM, NCONS>), dim3(grid), dim3(64 * (NCONS + 4)), lds, st, p, (const uint16_t*)p.w, n_mt, n_nt);
+    if (sch == 2) hipLaunchKernelGGL((k_conv_split_wsp<2, BM, NCONS>), dim3(grid), dim3(64 * (NCONS + 4)), lds, st, p, (const uint16_t*)p.w, n_mt, n_nt);
+    else if (sch == 1) hipLaunchKernelGGL((k_conv_split_wsp<1, BM, NCONS>), dim3(grid), dim3(64 * (NCONS + 4)), lds, st, p, (const uint16_t*)p.w, n_mt, n_nt);
+    else hipLaunchKernelGGL((k_conv_split_wsp<0, BM, NCONS>), dim3(grid), dim3(64 * (NCONS + 4)), lds, st, p, (const uint16_t*)p.w, n_mt, n_nt);
     return NDET_OK;
 }
 
@@ -1389,6 +1471,7 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
         // ---------------- producers ----------------
         const int stid = tid - 64 * NCONS;
         const int pw4 = wave - NCONS;
+        const float xs = SCH == 1 ? conv_xscale(p.amax_in) : 1.0f;
         // looped depth taps: the depth shift (kd - pd) rides in the scalar offset, the base pointer is moved back by pd slices
         const int64_t slice = (int64_t)p.H * p.W * p.Cin;
         const bool dloop = g.KDL > 1;
@@ -1448,9 +1531,7 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
                 const u32x4 u = ra[i];
                 uint2 s0, s1, s2;
                 const float4 xv = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
-                if (SCH == 1) spl_split4_f16(xv, p.xscale, s0, s1);
-                else if (SCH == 2) s0 = make_uint2(spl_pack(xv.x, xv.y), spl_pack(xv.z, xv.w));
-                else spl_split4(xv, s0, s1, s2);
+                spl_split<SCH>(xv, xs, s0, s1, s2);
                 if (adst[i] != ~0u) {
                     *reinterpret_cast<uint2*>(base + adst[i]) = s0;
                     if (NPL > 1) *reinterpret_cast<uint2*>(base + adst[i] + APL * 2) = s1;
@@ -1537,8 +1618,7 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
                         for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
                             for (int tb = 0; tb < NT16; ++tb) {
-                                if (SCH == 1) acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[pa][ta]), __builtin_bit_cast(f16x8, fb[pbb][tb]), acc[ta][tb], 0, 0, 0);
-                                else acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pa][ta], fb[pbb][tb], acc[ta][tb], 0, 0, 0);
+                                acc[ta][tb] = spl_mfma16<SCH>(fa[pa][ta], fb[pbb][tb], acc[ta][tb]);
                             }
                     }
                 if (++kw == wkw) {
@@ -1623,23 +1703,39 @@ static int split_launch_halo(const Conv3dParams& p, hipStream_t st, const char* 
     return NDET_OK;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool ONE = false>
-static int split_launch_tile(const Conv3dParams& p, hipStream_t st, const char* fn) {
+template <int BM, int BN, int WGM, int WGN, int SCH>
+static int split_launch_tile_sch(const Conv3dParams& p, hipStream_t st, const char* fn) {
     const int zdim = p.transposed ? 8 : p.splits;
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, zdim);
-    size_t lds = (size_t)(ONE ? 1 : 3) * (BM + BN) * SPL_RS * sizeof(uint16_t);
+    size_t lds = (size_t)Spl<SCH>::NPL * (BM + BN) * SPL_RS * sizeof(uint16_t);
     const size_t cs = (size_t)(BM / WGM) * (BN + 4) * sizeof(float);
     if (cs > lds) lds = cs;
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_conv_split<BM, BN, WGM, WGN, ONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute((const void*)k_conv_split<BM, BN, WGM, WGN, SCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL((k_conv_split<BM, BN, WGM, WGN, ONE>), grid, dim3(64 * WGM * WGN), lds, st, p, (const uint16_t*)p.w);
+    hipLaunchKernelGGL((k_conv_split<BM, BN, WGM, WGN, SCH>), grid, dim3(64 * WGM * WGN), lds, st, p, (const uint16_t*)p.w);
     return NDET_OK;
+}
+template <int BM, int BN, int WGM, int WGN>
+static int split_launch_tile(const Conv3dParams& p, hipStream_t st, const char* fn) {
+    switch (conv_scheme(p)) {
+        case 1: return split_launch_tile_sch<BM, BN, WGM, WGN, 1>(p, st, fn);
+        case 2: return split_launch_tile_sch<BM, BN, WGM, WGN, 2>(p, st, fn);
+        default: return split_launch_tile_sch<BM, BN, WGM, WGN, 0>(p, st, fn);
+    }
+}
+template <int NT16, int WGN>
+static int split_launch_halo_any(const Conv3dParams& p, hipStream_t st, const char* fn) {
+    switch (conv_scheme(p)) {
+        case 1: return split_launch_halo<NT16, WGN, 1>(p, st, fn);
+        case 2: return split_launch_halo<NT16, WGN, 2>(p, st, fn);
+        default: return split_launch_halo<NT16, WGN, 0>(p, st, fn);
+    }
 }
 
 #ifndef NDET_ORDER_DEFAULT
@@ -1670,19 +1766,16 @@ int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn)
     }
     int rc;
     switch (tile) {
-        case 64: rc = p.max_order == 0 ? split_launch_tile<64, 64, 2, 2, true>(p, st, fn) : split_launch_tile<64, 64, 2, 2>(p, st, fn); break;
-        case 128: rc = p.max_order == 0 ? split_launch_tile<128, 128, 2, 2, true>(p, st, fn) : split_launch_tile<128, 128, 2, 2>(p, st, fn); break;
-        case 12864: rc = p.max_order == 0 ? split_launch_tile<128, 64, 2, 2, true>(p, st, fn) : split_launch_tile<128, 64, 2, 2>(p, st, fn); break;
+        case 64: rc = split_launch_tile<64, 64, 2, 2>(p, st, fn); break;
+        case 128: rc = split_launch_tile<128, 128, 2, 2>(p, st, fn); break;
+        case 12864: rc = split_launch_tile<128, 64, 2, 2>(p, st, fn); break;
         case 128256: rc = split_launch_ws(p, st, fn); break;
         case 129256: rc = split_launch_wsp<128, 4>(p, st, fn); break;     // persistent form of 128256
         case 129257: rc = split_launch_wsp<128, 8>(p, st, fn); break;     // ... with eight consumer waves (two per SIMD, 64 x 64 each)
         case 129064: rc = split_launch_wsp<64, 4>(p, st, fn); break;      // ... with 64-row tiles
-        case 3128: rc = p.max_order == 0 ? split_launch_halo<4, 2, 2>(p, st, fn) : split_launch_halo<4, 2>(p, st, fn); break;
-        case 3256: rc = p.max_order == 0 ? split_launch_halo<8, 2, 2>(p, st, fn) : split_launch_halo<8, 2>(p, st, fn); break;
-        case 3257: rc = p.max_order == 0 ? split_launch_halo<4, 4, 2>(p, st, fn) : split_launch_halo<4, 4>(p, st, fn); break;
-        case 4128: rc = split_launch_halo<4, 2, 1>(p, st, fn); break;    // the same tiles on two fp16 planes / three products
-        case 4256: rc = split_launch_halo<8, 2, 1>(p, st, fn); break;
-        case 4257: rc = split_launch_halo<4, 4, 1>(p, st, fn); break;
+        case 3128: rc = split_launch_halo_any<4, 2>(p, st, fn); break;
+        case 3256: rc = split_launch_halo_any<8, 2>(p, st, fn); break;
+        case 3257: rc = split_launch_halo_any<4, 4>(p, st, fn); break;
         default: ndet_set_error("%s: unknown tile %d", fn, tile); return NDET_E_INVALID;
     }
     if (rc != NDET_OK) return rc;
@@ -1787,16 +1880,16 @@ extern "C" int ndet_split_weights_bf16x3_torch(const float* w_torch, int taps, i
     return NDET_OK;
 }
 
-static int conv_split_entry(const char* fn, int max_order, float xscale, const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin,
-                            int Cout, const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
-                            const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile, void* workspace,
-                            void* stream);
+static int conv_split_entry(const char* fn, int max_order, const float* in_amax, float w_inv_scale, float* out_amax, const float* in, const uint16_t* w_planes,
+                            float* out, int D, int H, int W, int Cin, int Cout, const int* kernel, const int* stride, const int* pad, int transposed,
+                            const float* scale, const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
+                            void* workspace, void* stream);
 
 extern "C" int ndet_conv_ndhwc_split(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
                                      const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
                                      const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
                                      void* workspace, void* stream) {
-    return conv_split_entry("ndet_conv_ndhwc_split", 2, 0.0f, in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, transposed, scale, shift, residual,
+    return conv_split_entry("ndet_conv_ndhwc_split", 2, nullptr, 1.0f, nullptr, in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, transposed, scale, shift, residual,
                             residual_up2, relu, splits, tile, workspace, stream);
 }
 
@@ -1804,30 +1897,59 @@ extern "C" int ndet_conv_ndhwc_bf16(const float* in, const uint16_t* w_planes, f
                                     const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
                                     const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
                                     void* workspace, void* stream) {
-    return conv_split_entry("ndet_conv_ndhwc_bf16", 0, 0.0f, in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, transposed, scale, shift, residual,
+    return conv_split_entry("ndet_conv_ndhwc_bf16", 0, nullptr, 1.0f, nullptr, in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, transposed, scale, shift, residual,
                             residual_up2, relu, splits, tile, workspace, stream);
 }
 
-extern "C" int ndet_conv_ndhwc_f16x2(const float* in, const uint16_t* w_planes_f16, float* out, int D, int H, int W, int Cin, int Cout,
-                                     const int* kernel, const int* stride, const int* pad, const float* scale, const float* shift,
-                                     const float* residual, int relu, int splits, int tile, float xscale, void* workspace, void* stream) {
-    const char* fn = "ndet_conv_ndhwc_f16x2";
-    NDET_REQUIRE(tile == 4128 || tile == 4256 || tile == 4257, NDET_E_INVALID, "%s: tile must be 4128, 4256 or 4257", fn);
-    NDET_REQUIRE(xscale > 0.0f, NDET_E_INVALID, "%s: xscale must be a positive power of two", fn);
-    return conv_split_entry(fn, 1, xscale, in, w_planes_f16, out, D, H, W, Cin, Cout, kernel, stride, pad, 0, scale, shift, residual, 0, relu, splits, tile,
-                            workspace, stream);
+extern "C" int ndet_conv_ndhwc_arith(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
+                                     const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
+                                     const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile, int arith,
+                                     const float* in_amax, float w_inv_scale, float* out_amax, void* workspace, void* stream) {
+    const char* fn = "ndet_conv_ndhwc_arith";
+    NDET_REQUIRE(arith >= 0 && arith <= 2, NDET_E_INVALID, "%s: arith must be 0 (bf16x3), 1 (fp16 pair) or 2 (bf16)", fn);
+    if (arith == 1) {
+        NDET_REQUIRE(in_amax != nullptr && w_inv_scale > 0.0f, NDET_E_INVALID, "%s: the fp16-pair arithmetic needs the input's amax slot and the weight planes' inverse scale", fn);
+    } else {
+        NDET_REQUIRE(in_amax == nullptr, NDET_E_INVALID, "%s: in_amax belongs to the fp16-pair arithmetic only", fn);
+    }
+    return conv_split_entry(fn, arith == 0 ? 2 : (arith == 1 ? 1 : 0), in_amax, arith == 1 ? w_inv_scale : 1.0f, out_amax, in, w_planes, out, D, H, W, Cin, Cout,
+                            kernel, stride, pad, transposed, scale, shift, residual, residual_up2, relu, splits, tile, workspace, stream);
 }
 
-static int conv_split_entry(const char* fn, int max_order, float xscale, const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin,
-                            int Cout, const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
-                            const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile, void* workspace,
-                            void* stream) {
+// max |x| of a tensor into a zeroed slot: the amax_in of a fp16-pair convolution whose input was not written by one of the convolution kernels
+__global__ __launch_bounds__(256) void k_amax(const float* __restrict__ x, int64_t n4, int64_t n, float* __restrict__ slot) {
+    float mx = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = n4 * 4; i < n; ++i) mx = fmaxf(mx, fabsf(x[i]));
+    conv_amax_commit(slot, mx);
+}
+
+extern "C" int ndet_amax_f32(const float* x, int64_t n, float* slot, void* stream) {
+    const char* fn = "ndet_amax_f32";
+    NDET_REQUIRE(x && slot && n > 0, NDET_E_INVALID, "%s: null pointer / empty tensor", fn);
+    NDET_REQUIRE(((uintptr_t)x & 15) == 0, NDET_E_UNSUPPORTED, "%s: x must be 16-byte aligned", fn);
+    const int64_t n4 = n / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_amax, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n4, n, slot);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
+
+static int conv_split_entry(const char* fn, int max_order, const float* in_amax, float w_inv_scale, float* out_amax, const float* in, const uint16_t* w_planes,
+                            float* out, int D, int H, int W, int Cin, int Cout, const int* kernel, const int* stride, const int* pad, int transposed,
+                            const float* scale, const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
+                            void* workspace, void* stream) {
     NDET_REQUIRE(in && w_planes && out && kernel && stride && pad, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
     NDET_REQUIRE((scale == nullptr) == (shift == nullptr), NDET_E_INVALID, "%s: scale and shift go together", fn);
     NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128 || tile == 12864 || tile == 128256 || tile == 129256 || tile == 129257 || tile == 129064 || tile == 3128 || tile == 3256 || tile == 3257 ||
-                                          tile == 100064 || tile == 100128 || tile == 112864 ||
-                                          (xscale > 0.0f && (tile == 4128 || tile == 4256 || tile == 4257))), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
+                                          tile == 100064 || tile == 100128 || tile == 112864), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
     NDET_REQUIRE(Cin % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
     NDET_REQUIRE((((uintptr_t)in | (uintptr_t)w_planes) & 15) == 0, NDET_E_UNSUPPORTED, "%s: in / weights must be 16-byte aligned", fn);
     Conv3dParams p;
@@ -1835,7 +1957,7 @@ static int conv_split_entry(const char* fn, int max_order, float xscale, const f
     p.partial = (float*)workspace;
     p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
     p.max_order = max_order;
-    p.xscale = xscale;
+    p.amax_in = in_amax; p.winv = w_inv_scale; p.amax_out = out_amax;
     if (transposed) {
         for (int a = 0; a < 3; ++a)
             NDET_REQUIRE(kernel[a] == 2 && stride[a] == 2 && pad[a] == 0, NDET_E_UNSUPPORTED, "%s: transposed conv supports kernel 2 stride 2 pad 0 only", fn);
@@ -1871,39 +1993,58 @@ static int conv_split_entry(const char* fn, int max_order, float xscale, const f
     return conv_split_launch(p, tile, (hipStream_t)stream, fn);
 }
 
-template <int MID, bool ONE>
+template <int MID, int SCH>
 static int chain_launch(const Conv3dParams& p, const ConvChain& c, hipStream_t st, const char* fn) {
-    constexpr int NPL = ONE ? 1 : 3;
+    constexpr int NPL = Spl<SCH>::NPL;
     size_t lds = (size_t)NPL * (128 + MID) * SPL_RS * sizeof(uint16_t);
     const size_t y = (size_t)NPL * (MID == 128 ? 64 : 128) * MID * sizeof(uint16_t);
     if (y > lds) lds = y;
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_conv_split_chain<MID, ONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute((const void*)k_conv_split_chain<MID, SCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL((k_conv_split_chain<MID, ONE>), dim3((p.M + 127) / 128), dim3(256), lds, st, p, (const uint16_t*)p.w, c);
+    hipLaunchKernelGGL((k_conv_split_chain<MID, SCH>), dim3((p.M + 127) / 128), dim3(256), lds, st, p, (const uint16_t*)p.w, c);
     return NDET_OK;
 }
+
+extern "C" int ndet_conv_chain_arith(const float* in, const uint16_t* w_planes, int D, int H, int W, int Cin, int Cmid, const int* kernel,
+                                     const int* stride, const int* pad, const float* scale1, const float* shift1, const uint16_t* w3_planes,
+                                     int Cout, const float* scale3, const float* shift3, const float* residual, int relu3, float* out,
+                                     int arith, const float* in_amax, float w1_inv_scale, float w3_inv_scale, float* out_amax, void* stream);
 
 extern "C" int ndet_conv_chain_split(const float* in, const uint16_t* w_planes, int D, int H, int W, int Cin, int Cmid, const int* kernel,
                                      const int* stride, const int* pad, const float* scale1, const float* shift1, const uint16_t* w3_planes,
                                      int Cout, const float* scale3, const float* shift3, const float* residual, int relu3, float* out,
                                      int max_order, void* stream) {
-    const char* fn = "ndet_conv_chain_split";
+    NDET_REQUIRE(max_order == 0 || max_order == 2, NDET_E_INVALID, "ndet_conv_chain_split: bad arithmetic");
+    return ndet_conv_chain_arith(in, w_planes, D, H, W, Cin, Cmid, kernel, stride, pad, scale1, shift1, w3_planes, Cout, scale3, shift3, residual, relu3, out,
+                                 max_order == 0 ? 2 : 0, nullptr, 1.0f, 1.0f, nullptr, stream);
+}
+
+extern "C" int ndet_conv_chain_arith(const float* in, const uint16_t* w_planes, int D, int H, int W, int Cin, int Cmid, const int* kernel,
+                                     const int* stride, const int* pad, const float* scale1, const float* shift1, const uint16_t* w3_planes,
+                                     int Cout, const float* scale3, const float* shift3, const float* residual, int relu3, float* out,
+                                     int arith, const float* in_amax, float w1_inv_scale, float w3_inv_scale, float* out_amax, void* stream) {
+    const char* fn = "ndet_conv_chain_arith";
+    NDET_REQUIRE(arith >= 0 && arith <= 2, NDET_E_INVALID, "%s: arith must be 0 (bf16x3), 1 (fp16 pair) or 2 (bf16)", fn);
+    NDET_REQUIRE((arith == 1) == (in_amax != nullptr), NDET_E_INVALID, "%s: in_amax goes with the fp16-pair arithmetic", fn);
+    NDET_REQUIRE(arith != 1 || (w1_inv_scale > 0.0f && w3_inv_scale > 0.0f), NDET_E_INVALID, "%s: the fp16-pair arithmetic needs the weight planes' inverse scales", fn);
+    const int max_order = arith == 0 ? 2 : (arith == 1 ? 1 : 0);
     NDET_REQUIRE(in && w_planes && w3_planes && out && kernel && stride && pad, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
     NDET_REQUIRE((scale1 == nullptr) == (shift1 == nullptr) && (scale3 == nullptr) == (shift3 == nullptr), NDET_E_INVALID, "%s: scale and shift go together", fn);
     NDET_REQUIRE(Cmid == 64 || Cmid == 128, NDET_E_UNSUPPORTED, "%s: the intermediate must have 64 or 128 channels (got %d)", fn, Cmid);
     NDET_REQUIRE(Cin % CBK == 0 && Cout % 64 == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d, Cout=%d of 64", fn, Cin, CBK, Cout);
-    NDET_REQUIRE(relu3 >= 0 && relu3 <= 2 && (max_order == 0 || max_order == 2), NDET_E_INVALID, "%s: bad relu mode / arithmetic", fn);
+    NDET_REQUIRE(relu3 >= 0 && relu3 <= 2, NDET_E_INVALID, "%s: bad relu mode", fn);
     NDET_REQUIRE((((uintptr_t)in | (uintptr_t)w_planes | (uintptr_t)w3_planes) & 15) == 0, NDET_E_UNSUPPORTED, "%s: in / weights must be 16-byte aligned", fn);
     Conv3dParams p;
     p.in = in; p.w = reinterpret_cast<const float*>(w_planes); p.out = nullptr; p.scale = scale1; p.shift = shift1; p.res = nullptr; p.partial = nullptr;
-    p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cmid; p.relu = 1; p.max_order = max_order; p.xscale = 1.0f;
+    p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cmid; p.relu = 1; p.max_order = max_order;
+    p.amax_in = in_amax; p.winv = w1_inv_scale;
     for (int a = 0; a < 3; ++a)
         NDET_REQUIRE(kernel[a] >= 1 && kernel[a] <= 7 && stride[a] >= 1 && stride[a] <= 4 && pad[a] >= 0 && pad[a] < kernel[a], NDET_E_UNSUPPORTED,
                      "%s: kernel/stride/pad out of range on axis %d", fn, a);
@@ -1921,10 +2062,11 @@ extern "C" int ndet_conv_chain_split(const float* in, const uint16_t* w_planes, 
     p.splits = 1; p.res_up2 = 0; p.RH = p.RW = 0;
     ConvChain c;
     c.w3 = w3_planes; c.scale3 = scale3; c.shift3 = shift3; c.res = residual; c.out = out; c.Cout3 = Cout; c.relu3 = relu3;
+    c.w3inv = arith == 1 ? w3_inv_scale : 1.0f; c.amax_out = out_amax;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (Cmid == 64) rc = max_order == 0 ? chain_launch<64, true>(p, c, st, fn) : chain_launch<64, false>(p, c, st, fn);
-    else rc = max_order == 0 ? chain_launch<128, true>(p, c, st, fn) : chain_launch<128, false>(p, c, st, fn);
+    if (Cmid == 64) rc = arith == 2 ? chain_launch<64, 2>(p, c, st, fn) : (arith == 1 ? chain_launch<64, 1>(p, c, st, fn) : chain_launch<64, 0>(p, c, st, fn));
+    else rc = arith == 2 ? chain_launch<128, 2>(p, c, st, fn) : (arith == 1 ? chain_launch<128, 1>(p, c, st, fn) : chain_launch<128, 0>(p, c, st, fn));
     if (rc != NDET_OK) return rc;
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
@@ -1968,7 +2110,7 @@ extern "C" int ndet_wgrad_split(const float* x_ndhwc, int D, int H, int W, int C
     p.in = nullptr; p.w = nullptr; p.out = dw_rows; p.scale = nullptr; p.shift = nullptr; p.res = nullptr; p.partial = (float*)workspace;
     p.D = p.H = p.W = 1; p.Cin = lrow; p.Cout = Cout; p.OD = p.OH = 1; p.OW = taps * Cin;
     p.kd = p.kh = p.kw = 1; p.sd = p.sh = p.sw = 1; p.pd = p.ph = p.pw = 0;
-    p.relu = 0; p.transposed = 0; p.M = taps * Cin; p.res_up2 = 0; p.RH = p.RW = 0; p.max_order = max_order; p.xscale = 1.0f;
+    p.relu = 0; p.transposed = 0; p.M = taps * Cin; p.res_up2 = 0; p.RH = p.RW = 0; p.max_order = max_order;
     p.splits = splits < 1 ? 1 : splits;
     NDET_REQUIRE(p.splits <= g.ksteps, NDET_E_INVALID, "%s: splits=%d exceeds the %d K steps", fn, p.splits, g.ksteps);
     NDET_REQUIRE(p.splits == 1 || workspace != nullptr, NDET_E_INVALID, "%s: split-K needs a workspace", fn);
