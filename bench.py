@@ -269,7 +269,7 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the static part of the step from hipGraphs (nerfdet_amd/graphed.py); measured equal to eager "
                          "launches within 1 %% on MI355X: the step is GPU-bound, launch-ahead already hides the gaps")
-    ap.add_argument("--conv-arithmetic", default=None, choices=["f32", "bf16x3", "bf16"],
+    ap.add_argument("--conv-arithmetic", default=None, choices=["f32", "bf16x3", "bf16", "f16x2"],
                     help="convolution kernel family (default: the package default, nerfdet_amd.conv3d.ARITHMETIC)")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -304,7 +304,7 @@ def main():
     state = {"step": 0}
     # ~150 conv launches per step: their event pairs cost ~2 % of the step, so they are sampled on every 4th timed step; the two
     # gather kernels and the five stage marks are recorded on every step
-    rec = trace.Recorder(sample=lambda name: (not name.startswith(("k_conv", "f32:", "bf16x3:"))) or state["step"] % 4 == 0)
+    rec = trace.Recorder(sample=lambda name: (not name.startswith(("k_conv", "f32:", "bf16x3:", "f16x2:", "bf16:"))) or state["step"] % 4 == 0)
 
     if args.graph:
         from nerfdet_amd.graphed import GraphedForwardTest
@@ -367,7 +367,19 @@ def main():
         traffic, traffic_src = measured_traffic(args.workload)
         conv_traffic = lambda name: traffic_of(traffic, name)
         bf16x3 = C3.ARITHMETIC == "bf16x3"
-        if C3.ARITHMETIC == "bf16":
+        # MFMA products issued per algorithmic multiply-add by a launch of the split family: 3 in the fp16-pair arithmetic, 6 in bf16x3
+        # (in f16x2 mode the layers below conv3d.F16_MIN_KSTEPS K steps run on bf16x3: their names carry no "/f16x2")
+        products = (lambda name: 3.0 if name.endswith("/f16x2") else 6.0) if C3.ARITHMETIC == "f16x2" else None
+        if C3.ARITHMETIC == "f16x2":
+            conv_kernel = ("k_conv_split in its fp16-pair mode (implicit-GEMM convolution on the fp16 matrix cores, fp32 operands as hi + lo fp16 pairs of "
+                           "the power-of-two pre-scaled tensors, 3 MFMA products per multiply, fp32 accumulate; layers with fewer than "
+                           f"{C3.F16_MIN_KSTEPS} K steps in the 6-product bf16x3 mode): 3D neck + head, ResNet/FPN; all tile instantiations, split-K reduce "
+                           "launches included in the event spans")
+            conv_peak = MFMA_BF16_PEAK_TFLOPS / 3.0
+            conv_peak_note = ("achieved = algorithmic fp32 convolution FLOPs / time; peak = dense fp16 MFMA peak 2500 TFLOP/s / issued products per "
+                              "algorithmic multiply-add (3 for the fp16-pair launches, 6 for the bf16x3 ones; for a mix of launches: the FLOP-weighted "
+                              "harmonic mean)")
+        elif C3.ARITHMETIC == "bf16":
             conv_kernel = ("k_conv_split in its one-product mode (implicit-GEMM convolution, both operands rounded to bf16, one bf16 MFMA product per "
                            "multiply, fp32 accumulate, fp32 activations in HBM): 3D neck + head, ResNet/FPN; all tile instantiations")
             conv_peak = MFMA_BF16_PEAK_TFLOPS
@@ -392,6 +404,10 @@ def main():
         conv_n = sum(v[2] for v in by_kernel.values())
         dom_name, (dom_flops, dom_ms, dom_n, dom_bytes) = max(by_kernel.items(), key=lambda kv: kv[1][1])
         dom_tflops = dom_flops / (dom_ms * 1e-3) / 1e12
+        dom_peak = all_peak = conv_peak
+        if products is not None:      # per-launch product counts: the time the matrix cores need at their peak sets the roof
+            dom_peak = MFMA_BF16_PEAK_TFLOPS / products(dom_name)
+            all_peak = conv_flops / sum(v[0] * products(k) / MFMA_BF16_PEAK_TFLOPS for k, v in by_kernel.items())
         mem = [(ms, i) for v in conv.values() for ms, i in v if i["flops"] / max(i["bytes"], 1) < ridge]
         mem_bytes, mem_ms = sum(i["bytes"] for _, i in mem), sum(ms for ms, _ in mem)
 
@@ -420,7 +436,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x3": "f32 (convolutions: fp32 operands as exact 3-term bf16 sums on the bf16 MFMA, fp32 accumulate)",
+            "dtype": {"f32": "f32", "f16x2": "f32 (convolutions: fp32 operands as hi + lo fp16 pairs of the power-of-two pre-scaled tensors, three products per "
+                               "multiply on the fp16 MFMA, fp32 accumulate; error against fp64 at or below the six-product bf16x3 form's)",
+                      "bf16x3": "f32 (convolutions: fp32 operands as exact 3-term bf16 sums on the bf16 MFMA, fp32 accumulate)",
                       "bf16": "bf16 (convolution operands rounded to bf16 on the MFMA, fp32 accumulate; activations, projection, aggregation, "
                               "NMS fp32 -- SURVEY.md 0.1)"}[C3.ARITHMETIC],
             "data": "synthetic",
@@ -430,15 +448,15 @@ def main():
                        "scenes_per_step": world, "parallelism": f"scene replicas x{world} (no data-path collective)"},
             "roofline": {"kernel": f"{dom_name} (the convolution instantiation with the largest share of the step; event spans include the "
                                    f"split-K reduce launch where a layer splits K)",
-                         "bound": "mfma", "achieved": dom_tflops, "peak": conv_peak, "unit": "TFLOP/s",
-                         "frac": dom_tflops / conv_peak, "traffic": conv_traffic(dom_name),
+                         "bound": "mfma", "achieved": dom_tflops, "peak": dom_peak, "unit": "TFLOP/s",
+                         "frac": dom_tflops / dom_peak, "traffic": conv_traffic(dom_name),
                          "traffic_source": None if conv_traffic(dom_name) is None else traffic_src, "peak_note": conv_peak_note,
                          "algorithmic_flops_per_launch": dom_flops / dom_n, "algorithmic_bytes_per_launch": dom_bytes / dom_n,
                          "launches_per_step": dom_n / n_conv_steps,
                          "avg_launch_ms": dom_ms / dom_n, "total_ms_per_step": dom_ms / n_conv_steps, "sampled_steps": n_conv_steps},
             "roofline_all_convolutions": {"kernel": conv_kernel,
-                         "bound": "mfma", "achieved": conv_flops / (conv_ms * 1e-3) / 1e12, "peak": conv_peak, "unit": "TFLOP/s",
-                         "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / conv_peak, "traffic": None, "peak_note": conv_peak_note,
+                         "bound": "mfma", "achieved": conv_flops / (conv_ms * 1e-3) / 1e12, "peak": all_peak, "unit": "TFLOP/s",
+                         "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / all_peak, "traffic": None, "peak_note": conv_peak_note,
                          "algorithmic_flops_per_step": conv_flops / n_conv_steps, "launches_per_step": conv_n / n_conv_steps,
                          "avg_launch_ms": conv_ms / conv_n, "total_ms_per_step": conv_ms / n_conv_steps,
                          "sampled_steps": n_conv_steps,

@@ -190,48 +190,51 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void k_co
                 Cs[(wm * WM + ta * 16 + (lane >> 4) * 4 + r) * CLDC + wn * WN + tb * 16 + (lane & 15)] = acc[ta][tb][r];
     __syncthreads();
 
-    conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0, BM, n0, tid, ztap, blockIdx.z);
+    float mx = 0.0f;
+    conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0, BM, n0, tid, ztap, blockIdx.z, mx);
+    if (p.amax_out && conv_writes_final(p)) conv_amax_commit(p.amax_out, mx);
 }
 
-// fixed-order reduction of the split-K partials + epilogue
+// fixed-order reduction of the split-K partials + epilogue (grid-stride: at most 1024 workgroups, one amax atomic each at most)
 __global__ __launch_bounds__(256) void k_conv3d_splitk_reduce(const float* __restrict__ partial, int splits, int64_t MN, int Cout,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ res, int relu, float* __restrict__ out,
                                                               float* __restrict__ amax_out) {
-    // VEC = 4 when Cout % 4 == 0 (host picks the grid accordingly): one float4 per thread
+    // VEC = 4 when Cout % 4 == 0: one float4 per thread and pass
     const bool vec = (Cout & 3) == 0;
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * (vec ? 4 : 1);
+    const int64_t step = (int64_t)gridDim.x * blockDim.x * (vec ? 4 : 1);
     float mx = 0.0f;
-    if (i >= MN) {
-    } else if (vec) {
-        float4 v = *reinterpret_cast<const float4*>(partial + i);
-        for (int s = 1; s < splits; ++s) {
-            const float4 t = *reinterpret_cast<const float4*>(partial + (int64_t)s * MN + i);
-            v.x = v.x + t.x; v.y = v.y + t.y; v.z = v.z + t.z; v.w = v.w + t.w;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * (vec ? 4 : 1); i < MN; i += step) {
+        if (vec) {
+            float4 v = *reinterpret_cast<const float4*>(partial + i);
+            for (int s = 1; s < splits; ++s) {
+                const float4 t = *reinterpret_cast<const float4*>(partial + (int64_t)s * MN + i);
+                v.x = v.x + t.x; v.y = v.y + t.y; v.z = v.z + t.z; v.w = v.w + t.w;
+            }
+            const int co = (int)(i % Cout);
+            if (scale) {
+                const float4 sc = *reinterpret_cast<const float4*>(scale + co), sh = *reinterpret_cast<const float4*>(shift + co);
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+            }
+            if (relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (res) {
+                const float4 rr = *reinterpret_cast<const float4*>(res + i);
+                v.x = v.x + rr.x; v.y = v.y + rr.y; v.z = v.z + rr.z; v.w = v.w + rr.w;
+            }
+            if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(out + i) = v;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        } else {
+            float v = partial[i];
+            for (int s = 1; s < splits; ++s) v = v + partial[(int64_t)s * MN + i];
+            const int co = (int)(i % Cout);
+            if (scale) v = v * scale[co] + shift[co];
+            if (relu == 2) v = fmaxf(v, 0.0f);
+            if (res) v = v + res[i];
+            if (relu == 1) v = fmaxf(v, 0.0f);
+            out[i] = v;
+            mx = fmaxf(mx, fabsf(v));
         }
-        const int co = (int)(i % Cout);
-        if (scale) {
-            const float4 sc = *reinterpret_cast<const float4*>(scale + co), sh = *reinterpret_cast<const float4*>(shift + co);
-            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-        }
-        if (relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (res) {
-            const float4 rr = *reinterpret_cast<const float4*>(res + i);
-            v.x = v.x + rr.x; v.y = v.y + rr.y; v.z = v.z + rr.z; v.w = v.w + rr.w;
-        }
-        if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<float4*>(out + i) = v;
-        mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    } else {
-        float v = partial[i];
-        for (int s = 1; s < splits; ++s) v = v + partial[(int64_t)s * MN + i];
-        const int co = (int)(i % Cout);
-        if (scale) v = v * scale[co] + shift[co];
-        if (relu == 2) v = fmaxf(v, 0.0f);
-        if (res) v = v + res[i];
-        if (relu == 1) v = fmaxf(v, 0.0f);
-        out[i] = v;
-        mx = fabsf(v);
     }
     if (amax_out) conv_amax_commit(amax_out, mx);
 }
@@ -272,7 +275,9 @@ int conv_splitk_reduce_launch(const Conv3dParams& p, hipStream_t st, const char*
     if (p.transposed || p.splits <= 1) return NDET_OK;
     const int64_t mn = (int64_t)p.M * p.Cout;
     const int64_t work = (p.Cout & 3) == 0 ? mn / 4 : mn;
-    hipLaunchKernelGGL(k_conv3d_splitk_reduce, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, p.partial, p.splits, mn, p.Cout, p.scale,
+    int64_t blocks = (work + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_conv3d_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, st, p.partial, p.splits, mn, p.Cout, p.scale,
                        p.shift, p.res, p.relu, p.out, p.amax_out);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;

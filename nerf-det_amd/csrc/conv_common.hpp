@@ -57,12 +57,25 @@ __device__ __forceinline__ float conv_xinv(const float* amax) { return conv_xinv
 // what the accumulators are multiplied by before the epilogue's affine: 1 except in the fp16-pair arithmetic (exact: a power of two)
 __device__ __forceinline__ float conv_oscale(const Conv3dParams& p) { return p.amax_in ? conv_xinv(p.amax_in) * p.winv : 1.0f; }
 
-// max |v| of a wave -> one atomic on the layer's amax slot (non-negative floats order like their bit patterns).  Every lane of the
-// wave must arrive.
+// max |v| of a WORKGROUP -> at most one atomic on the layer's amax slot (non-negative floats order like their bit patterns).  Device-scope
+// atomics on one address are performed memory-side, one after the other (~5 ns each: one per wave cost a 240 000-row layer 70 us), so the
+// workgroup reduces in LDS first, then READS the slot (agent scope: served where the atomics are performed -- a plain load hits the XCD's own
+// L2 line, which never sees them) and only sends its maximum when it is larger: the slot only grows, so a stale value costs a needless
+// atomic, never a missed one, and after the first round of workgroups almost nobody has a new maximum.  Every thread of the workgroup
+// must arrive (there is a barrier inside).
 __device__ __forceinline__ void conv_amax_commit(float* slot, float mx) {
+    __shared__ float wg_amax[16];
 #pragma unroll
     for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(mx));
+    const int nw = ((int)blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) wg_amax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < nw; ++i) mx = fmaxf(mx, wg_amax[i]);
+        const unsigned bits = __float_as_uint(mx);
+        if (bits > __hip_atomic_load(reinterpret_cast<const unsigned*>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(reinterpret_cast<unsigned*>(slot), bits);
+    }
 }
 
 // internal launchers (one per kernel family) and the shared split-K reduction
@@ -99,13 +112,13 @@ struct ConvLinearRows {
     __device__ __forceinline__ int operator()(int row) const { return first + row; }
 };
 
+// `mx`: running max |v| of the final values this thread stored (the caller commits it once, conv_amax_commit).
 template <int BN, int NTHR, typename RowMap>
 __device__ __forceinline__ void conv_store_rows_mapped(const Conv3dParams& p, const float* Cs, int cld, int rows, int n0, int tid, int ztap,
-                                                       int zsplit, RowMap m_of) {
+                                                       int zsplit, RowMap m_of, float& mx) {
     const bool raw = (!p.transposed && p.splits > 1);
     float* dst = raw ? p.partial + (int64_t)zsplit * p.M * p.Cout : p.out;
     const float osc = conv_oscale(p);
-    float mx = 0.0f;
     auto res_row = [&](int m, int64_t orow) -> int64_t {
         if (!p.res_up2) return orow;
         const int ow = m % p.OW, oh = (m / p.OW) % p.OH, od = m / (p.OW * p.OH);
@@ -152,12 +165,13 @@ __device__ __forceinline__ void conv_store_rows_mapped(const Conv3dParams& p, co
             dst[orow * p.Cout + co] = v;
         }
     }
-    if (p.amax_out && !raw) conv_amax_commit(p.amax_out, mx);   // (split-K: the reduce pass sees the final values)
 }
 
 // tile rows are consecutive GEMM rows starting at m_first
 template <int BN, int NTHR>
 __device__ __forceinline__ void conv_store_rows(const Conv3dParams& p, const float* Cs, int cld, int m_first, int rows, int n0, int tid,
-                                                int ztap, int zsplit) {
-    conv_store_rows_mapped<BN, NTHR>(p, Cs, cld, rows, n0, tid, ztap, zsplit, ConvLinearRows{m_first});
+                                                int ztap, int zsplit, float& mx) {
+    conv_store_rows_mapped<BN, NTHR>(p, Cs, cld, rows, n0, tid, ztap, zsplit, ConvLinearRows{m_first}, mx);
 }
+// does this launch's epilogue write the layer's final values (split-K launches write partials: their reduce pass commits the maximum)
+__device__ __forceinline__ bool conv_writes_final(const Conv3dParams& p) { return p.transposed || p.splits <= 1; }

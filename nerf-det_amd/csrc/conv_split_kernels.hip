@@ -352,6 +352,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
     // ---- epilogue: accumulators -> LDS (one wave-row of the tile at a time) -> fused row-wise stores ----
     constexpr int CLDC = BN + 4;
     float* Cs = reinterpret_cast<float*>(lds16);   // [WM][CLDC] floats <= the operand planes
+    float mx = 0.0f;
     for (int h = 0; h < WGM; ++h) {
         if (wm == h) {
 #pragma unroll
@@ -363,9 +364,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
                         Cs[(ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CLDC + wn * WN + tb * 32 + (lane & 31)] = acc[ta][tb][r];
         }
         __syncthreads();
-        conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, ztap, blk.z);
+        conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, ztap, blk.z, mx);
         __syncthreads();
     }
+    if (p.amax_out && conv_writes_final(p)) conv_amax_commit(p.amax_out, mx);
 }
 
 
@@ -758,7 +760,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(const WgradParams g, con
                         Cs[(ta_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CLDC + wn * WN + tb_ * 32 + (lane & 31)] = acc[ta_][tb_][r];
         }
         __syncthreads();
-        conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, 0, blockIdx.z);
+        float mx_unused = 0.0f;
+        conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, 0, blockIdx.z, mx_unused);
         __syncthreads();
     }
 }
@@ -1013,6 +1016,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
     // ---- epilogue (all 8 waves store): one 64-row half of the tile at a time through LDS ----
     constexpr int CLDC = WS_BN + 4;
     float* Cs = reinterpret_cast<float*>(lds16);
+    float mx = 0.0f;
     for (int h = 0; h < 2; ++h) {
         if (consumer && wm == h) {
             // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -1025,9 +1029,10 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
                         Cs[(ta * 16 + (lane >> 4) * 4 + r) * CLDC + wn * 128 + tb * 16 + (lane & 15)] = acc[ta][tb][r];
         }
         __syncthreads();
-        conv_store_rows<WS_BN, 512>(p, Cs, CLDC, m0 + h * 64, 64, n0, tid, ztap, blk.z);
+        conv_store_rows<WS_BN, 512>(p, Cs, CLDC, m0 + h * 64, 64, n0, tid, ztap, blk.z, mx);
         __syncthreads();
     }
+    if (p.amax_out && conv_writes_final(p)) conv_amax_commit(p.amax_out, mx);
 }
 
 // arithmetic scheme of a launch (Spl): max_order 2 = bf16x3, 1 = fp16 pair, 0 = one bf16 product
@@ -1635,6 +1640,7 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
     // ---- epilogue (all 8 waves store): one 64-row half of the patch at a time through LDS ----
     constexpr int CLDC = BN + 4;
     float* Cs = reinterpret_cast<float*>(lds16);
+    float mx = 0.0f;
     for (int h = 0; h < 2; ++h) {
         if (consumer && wm == h) {
 #pragma unroll
@@ -1646,9 +1652,10 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
                         Cs[(ta * 16 + (lane >> 4) * 4 + r) * CLDC + wn * (16 * NT16) + tb * 16 + (lane & 15)] = acc[ta][tb][r];
         }
         __syncthreads();
-        conv_store_rows_mapped<BN, NTHR>(p, Cs, CLDC, 64, n0, tid, 0, blk.z, HaloRowMap{h * 64, g.ltw, g.lth, d0, h0, w0, p.OD, p.OH, p.OW});
+        conv_store_rows_mapped<BN, NTHR>(p, Cs, CLDC, 64, n0, tid, 0, blk.z, HaloRowMap{h * 64, g.ltw, g.lth, d0, h0, w0, p.OD, p.OH, p.OW}, mx);
         __syncthreads();
     }
+    if (p.amax_out && conv_writes_final(p)) conv_amax_commit(p.amax_out, mx);
 }
 
 // patch shape for the halo tile: the power-of-two TD x TH x TW = 128 with the least padded work (weighted by the halo it drags)

@@ -9,6 +9,9 @@ w = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
 if len(sys.argv) > 2 and sys.argv[2] == "nochain":     # layer_times.py cfg2 nochain: conv2 / conv3 of the bottlenecks as two launches
     from nerfdet_amd import conv3d
     conv3d.CHAIN_BOTTLENECKS = False
+if len(sys.argv) > 2 and sys.argv[2] in ("f16x2", "bf16x3", "bf16", "f32"):     # layer_times.py cfg2 f16x2
+    from nerfdet_amd import conv3d
+    conv3d.set_arithmetic(sys.argv[2])
 dev = torch.device("cuda")
 det = bench.build_model(w).to(dev)
 batch = bench.to_device(bench.synth_batch(w, 0), dev)
@@ -27,11 +30,13 @@ with torch.no_grad():
 n = len(recs[0])
 assert all(len(r) == n for r in recs)
 tot = 0.0
-print(f"{'#':>3} {'kernel':32s} {'ms':>7s} {'GF':>7s} {'MB':>7s} {'TF/s':>6s} {'GB/s':>6s}")
+print(f"{'#':>3} {'kernel':38s} {'ms':>7s} {'GF':>7s} {'MB':>7s} {'TF/s':>6s} {'GB/s':>6s}")
 for i in range(n):
     name, _, info = recs[0][i]
     ms = sorted(r[i][1] for r in recs)[steps // 2]
     tot += ms
     fl, by = info.get("flops", 0), info.get("bytes", 0)
-    print(f"{i:3d} {name[:32]:32s} {ms:7.3f} {fl / 1e9:7.1f} {by / 1e6:7.1f} {fl / ms / 1e9 if fl else 0:6.1f} {by / ms / 1e6:6.0f}")
+    print(f"{i:3d} {name[:38]:38s} {ms:7.3f} {fl / 1e9:7.1f} {by / 1e6:7.1f} {fl / ms / 1e9 if fl else 0:6.1f} {by / ms / 1e6:6.0f}")
 print("sum of spans", round(tot, 3), "ms")
+from nerfdet_amd import conv3d as _c
+print("amax fallbacks per step", _c.amax_fallbacks / (4 + steps))
