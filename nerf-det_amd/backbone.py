@@ -46,7 +46,7 @@ class Bottleneck(nn.Module):
         """Inference form on (N,H,W,C): every conv carries its frozen BatchNorm, ReLU and (last one) the residual
         add in the MFMA kernel's epilogue -- 4 kernels instead of 4 convs + 10 elementwise passes."""
         y = conv2d_nhwc(x, packed([self.conv1], self.bn1), relu=1)
-        idt = x if self.downsample is None else conv2d_nhwc(x, packed([self.downsample[0]], self.downsample[1]))
+        idt = x if self.downsample is None else conv2d_nhwc(x, packed([self.downsample[0]], self.downsample[1]), amax=False)
         pk2, pk3 = packed([self.conv2], self.bn2), packed([self.conv3], self.bn3)
         if chain_ok(pk2, pk3):          # stages 1 / 2: the 64- / 128-channel intermediate never leaves the CU
             return conv2d_chain_nhwc(y, pk2, pk3, residual=idt, relu=1)
@@ -248,4 +248,4 @@ class FPN(nn.Module):
             lat[i] = conv2d_nhwc(_nhwc(inputs[i]), packed([self.lateral_convs[i].conv]), residual=lat[i + 1] if i + 1 < n else None,
                                  residual_up2=i + 1 < n)
         act = range(n) if self.active_outs is None else self.active_outs
-        return tuple(conv2d_nhwc(lat[i], packed([self.fpn_convs[i].conv])).permute(0, 3, 1, 2) if i in act else None for i in range(n))
+        return tuple(conv2d_nhwc(lat[i], packed([self.fpn_convs[i].conv]), amax=False).permute(0, 3, 1, 2) if i in act else None for i in range(n))

@@ -28,7 +28,7 @@ from .conv_tuning import TUNED, TUNED_BF16, TUNED_F16, TUNED_SPLIT
 # roundings per K step instead of six; tests/test_conv3d_gpu.py::test_f16x2_error_not_above_bf16x3).  The activation scale is derived on the
 # device from the input's max |x|, which every convolution epilogue leaves behind for the next layer (the `_ndet_amax` attribute of its output
 # tensor); layers with fewer than F16_MIN_KSTEPS K steps stay on bf16x3 (HBM-bound: nothing to gain), training stays on bf16x3.
-ARITHMETIC = "bf16x3"
+ARITHMETIC = "f16x2"
 F16_MIN_KSTEPS = 4
 SPLIT_FAMILY = ("bf16x3", "bf16", "f16x2")    # the arithmetics of csrc/conv_split_kernels.hip
 
@@ -48,8 +48,11 @@ def train_arithmetic() -> str:
 
 
 class _AmaxSlots:
-    """One-float device slots for the tensors' max |x| (fp16-pair arithmetic).  A slot is handed out once and never reused: it has to be zero
-    before the producing launch, and the zeros come from one fill per 4096 slots, stream-ordered before every launch that follows on that stream."""
+    """Device slots (1 KiB: one sub-slot per XCD) for the tensors' max |x| (fp16-pair arithmetic).  A slot is handed out once and never reused: it
+    has to be zero before the producing launch, and the zeros come from one fill per 4096 slots, stream-ordered before every launch that follows
+    on that stream."""
+
+    WIDTH = 256     # floats per slot: 8 sub-slots (one per XCD) 128 bytes apart (csrc/conv_common.hpp::conv_amax_commit / conv_amax_read)
 
     def __init__(self):
         self.pools = {}
@@ -57,10 +60,10 @@ class _AmaxSlots:
     def take(self, device) -> torch.Tensor:
         key = (device, torch.cuda.current_stream(device).cuda_stream)
         pool = self.pools.get(key)
-        if pool is None or pool[1] >= pool[0].numel():
-            pool = self.pools[key] = [torch.zeros(4096, dtype=torch.float32, device=device), 0]
-        slot = pool[0][pool[1]:pool[1] + 1]
-        pool[1] += 1
+        if pool is None or pool[1] + self.WIDTH > pool[0].numel():
+            pool = self.pools[key] = [torch.zeros(4096 * self.WIDTH, dtype=torch.float32, device=device), 0]
+        slot = pool[0][pool[1]:pool[1] + self.WIDTH]
+        pool[1] += self.WIDTH
         return slot
 
     def fresh(self, device):
@@ -78,6 +81,11 @@ def carry_amax(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     if slot is not None:
         dst._ndet_amax = slot
     return dst
+
+
+def amax_value(slot: torch.Tensor) -> float:
+    """Host read-back of a slot (tests / diagnostics; synchronises)."""
+    return float(slot.view(-1, 32)[:, 0].max())
 
 
 def amax_of(x: torch.Tensor) -> torch.Tensor:
@@ -215,7 +223,7 @@ def layer_arithmetic(k_iters: int) -> str:
     return ARITHMETIC
 
 
-def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, residual_up2, relu, splits, tile, m, k_iters, flops):
+def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, residual_up2, relu, splits, tile, m, k_iters, flops, want_amax=True):
     halo_ok = (not transposed and all(s == 1 for s in stride) and all(k % 2 == 1 and q == k // 2 for k, q in zip(kernel, pad))
                and kernel[0] * kernel[1] * kernel[2] > 1)
     tile, splits = choose_tiling_split(m, pk["cout"], k_iters, tile, 1 if (transposed or residual_up2) else splits, transposed, halo_ok)
@@ -252,12 +260,13 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
         in_amax = amax_of(x)
     else:
         planes, winv, in_amax = split_planes(pk), 1.0, None
-    out_amax = AMAX.take(x.device)
+    out_amax = AMAX.take(x.device) if want_amax else None
     _launch(flops, lambda: check(lib.ndet_conv_ndhwc_arith(_ptr(x), _ptr(planes), _ptr(out), d, h, w, pk["cin"], pk["cout"], i3(kernel), i3(stride), i3(pad),
                                                            int(transposed), _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), int(residual_up2), relu,
                                                            splits, tile, 1 if arith == "f16x2" else 0, _ptr(in_amax), winv, _ptr(out_amax), _ptr(ws), st),
                                  "conv_ndhwc_arith"), arith, tile, nbytes)
-    out._ndet_amax = out_amax
+    if want_amax:
+        out._ndet_amax = out_amax
     return out
 
 
@@ -358,8 +367,10 @@ def linear_rows(x: torch.Tensor, pk: dict, relu: int = 0) -> torch.Tensor:
     return carry_amax(y, y.view(x.shape[0], -1))
 
 
-def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = None, relu: int = 0, splits: int = 0, tile: int = 0):
-    """x (D,H,W,Cin) contiguous fp32 on the GPU -> (OD,OH,OW,Cout).  relu: 0 none, 1 after the residual add, 2 before it."""
+def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = None, relu: int = 0, splits: int = 0, tile: int = 0,
+                 amax: bool = True):
+    """x (D,H,W,Cin) contiguous fp32 on the GPU -> (OD,OH,OW,Cout).  relu: 0 none, 1 after the residual add, 2 before it.  amax (fp16-pair
+    mode): leave max |out| behind for a following convolution -- False for outputs no convolution reads (identity branches, final heads)."""
     if not x.is_cuda:
         raise RuntimeError("nerfdet_amd.conv3d: tensors must live on the GPU (no CPU fallback)")
     assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
@@ -381,7 +392,7 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
     if ARITHMETIC in SPLIT_FAMILY:
         kk, ss, pp = ((2, 2, 2), (2, 2, 2), (0, 0, 0)) if tr else ((k,) * 3, (s,) * 3, (pad,) * 3)
         return _conv_split(x, pk, out, (d, h, w), kk, ss, pp, tr, residual, False, relu, splits, tile, m,
-                           (cin // 32) * (1 if tr else k ** 3), flops)
+                           (cin // 32) * (1 if tr else k ** 3), flops, amax)
     if tr:
         tile, splits = (tile or choose_tiling(m, cout, cin // 32, 0, 0, True)[0]), 1
     else:
@@ -397,7 +408,7 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
 
 
 def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = None, relu: int = 0, splits: int = 0, tile: int = 0,
-                residual_up2: bool = False):
+                residual_up2: bool = False, amax: bool = True):
     """Batch of 2D maps, x (N,H,W,Cin) contiguous fp32 -> (N,OH,OW,Cout): Conv2d (+ eval BatchNorm2d / bias) + ReLU +
     residual in one pass of the MFMA kernel (the batch is the kernel's depth axis with extent-1 taps)."""
     if not x.is_cuda:
@@ -416,7 +427,7 @@ def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = No
     m = n * oh * ow
     if ARITHMETIC in SPLIT_FAMILY:
         return _conv_split(x, pk, out, (n, h, w), (1, kh, kw), (1, sh, sw), (0, ph, pw), False, residual, residual_up2, relu, splits, tile, m,
-                           kh * kw * (cin // 32), 2 * m * cout * cin * kh * kw)
+                           kh * kw * (cin // 32), 2 * m * cout * cin * kh * kw, amax)
     tile, splits = choose_tiling(m, cout, kh * kw * (cin // 32), tile, splits)
     ws = torch.empty((m * cout * splits * 4,), dtype=torch.uint8, device=x.device) if splits > 1 else None
     i3 = lambda a, b, c: (ctypes.c_int * 3)(a, b, c)

@@ -34,11 +34,29 @@ struct Conv3dParams {
     // fp16-pair arithmetic (max_order == 1; conv_split_kernels.hip, SCH 1): both operands are pre-scaled by a power of two so that their largest
     // magnitude sits in [2^14, 2^15) -- the weights once, when their planes are built (`winv` = 1 / that scale), the activations while
     // they are split, by the scale the kernel derives from `amax_in`; the epilogue multiplies the accumulators by the inverse of both.
-    const float* amax_in = nullptr;   // device: max |in| over the whole input tensor (any upper bound within ~2^10 of it serves)
+    const float* amax_in = nullptr;   // device: the input tensor's amax slot (8 per-XCD sub-slots, see conv_amax_read below)
     float winv = 1.0f;                // 1 / (weight scale)
-    float* amax_out = nullptr;        // any arithmetic, optional: max |out| is atomically maxed into *amax_out (as uint bits: the slot must be zeroed
-                                      // by the caller before the launch) -- the next layer's amax_in without another pass over the tensor
+    float* amax_out = nullptr;        // any arithmetic, optional: max |out| is atomically maxed into the slot at amax_out (1 KiB, zeroed by the caller
+                                      // before the launch) -- the next layer's amax_in without another pass over the tensor
 };
+
+// ---- the amax slot of a tensor: 8 sub-slots, one per XCD, each in a 128-byte line of its own (256 floats = 1 KiB per slot) ----
+// The L2s of the eight XCDs are kept coherent line by line: a line that workgroups on different XCDs update (atomics or stores) migrates
+// between the L2s on every access -- measured: one atomic per wave on ONE address cost a 240 000-row layer 70 us, and a per-XCD hint word
+// sharing its line with the other XCDs' hints cost more than it saved.  Here a workgroup touches only the sub-slot of the XCD it runs on
+// (hardware register XCC_ID), so the line stays in that L2 and the atomic is an L2-local operation; the reader takes the maximum of the
+// eight sub-slots (read-only by then: shared copies, no migration).
+#define NDET_AMAX_SUB 8
+#define NDET_AMAX_STRIDE 32     // floats between sub-slots (128 bytes)
+__device__ __forceinline__ unsigned conv_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; }   // HW_REG_XCC_ID[3:0]
+
+// max |x| of the tensor behind `slot` (uniform: every lane reads one sub-slot, an 8-lane butterfly finishes)
+__device__ __forceinline__ float conv_amax_read(const float* slot) {
+    float v = slot[(threadIdx.x & (NDET_AMAX_SUB - 1)) * NDET_AMAX_STRIDE];
+#pragma unroll
+    for (int o = NDET_AMAX_SUB / 2; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
+}
 
 // Power-of-two activation scale of the fp16-pair kernels and its inverse, from the tensor's max |x| = m 2^(eb-126), m in [1/2, 1):
 // x * conv_xscale < 2^15.  Tensors whose maximum is below 2^-97 (eb < 30) are scaled by 2^111: no overflow of the scale itself.
@@ -52,17 +70,14 @@ __device__ __forceinline__ float conv_xinv_of(float amax) {
     eb = eb < 30 ? 30 : eb;
     return __uint_as_float((unsigned)(eb - 14) << 23);
 }
-__device__ __forceinline__ float conv_xscale(const float* amax) { return conv_xscale_of(*amax); }
-__device__ __forceinline__ float conv_xinv(const float* amax) { return conv_xinv_of(*amax); }
-// what the accumulators are multiplied by before the epilogue's affine: 1 except in the fp16-pair arithmetic (exact: a power of two)
-__device__ __forceinline__ float conv_oscale(const Conv3dParams& p) { return p.amax_in ? conv_xinv(p.amax_in) * p.winv : 1.0f; }
+__device__ __forceinline__ float conv_xscale(const float* amax) { return conv_xscale_of(conv_amax_read(amax)); }
+// what the accumulators are multiplied by before the epilogue's affine: 1 except in the fp16-pair arithmetic (exact: a power of two).
+// Every lane of the calling wave must be active (conv_amax_read shuffles).
+__device__ __forceinline__ float conv_oscale(const Conv3dParams& p) { return p.amax_in ? conv_xinv_of(conv_amax_read(p.amax_in)) * p.winv : 1.0f; }
 
-// max |v| of a WORKGROUP -> at most one atomic on the layer's amax slot (non-negative floats order like their bit patterns).  Device-scope
-// atomics on one address are performed memory-side, one after the other (~5 ns each: one per wave cost a 240 000-row layer 70 us), so the
-// workgroup reduces in LDS first, then READS the slot (agent scope: served where the atomics are performed -- a plain load hits the XCD's own
-// L2 line, which never sees them) and only sends its maximum when it is larger: the slot only grows, so a stale value costs a needless
-// atomic, never a missed one, and after the first round of workgroups almost nobody has a new maximum.  Every thread of the workgroup
-// must arrive (there is a barrier inside).
+// max |v| of a WORKGROUP -> one L2-local atomic on this XCD's sub-slot, skipped when the sub-slot already holds as much (non-negative floats
+// order like their bit patterns; the sub-slot only grows, so a stale read costs a needless atomic, never a missed one).  Every thread of the
+// workgroup must arrive (there is a barrier inside).
 __device__ __forceinline__ void conv_amax_commit(float* slot, float mx) {
     __shared__ float wg_amax[16];
 #pragma unroll
@@ -73,8 +88,8 @@ __device__ __forceinline__ void conv_amax_commit(float* slot, float mx) {
     if (threadIdx.x == 0) {
         for (int i = 1; i < nw; ++i) mx = fmaxf(mx, wg_amax[i]);
         const unsigned bits = __float_as_uint(mx);
-        if (bits > __hip_atomic_load(reinterpret_cast<const unsigned*>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(reinterpret_cast<unsigned*>(slot), bits);
+        unsigned* sub = reinterpret_cast<unsigned*>(slot) + conv_xcc_id() * NDET_AMAX_STRIDE;
+        if (bits > __builtin_nontemporal_load(sub)) atomicMax(sub, bits);
     }
 }
 

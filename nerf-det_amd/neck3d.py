@@ -39,7 +39,7 @@ class BasicBlock3dV2(nn.Module):
     def forward_ndhwc(self, x):
         """x (D,H,W,C) -> (D',H',W',C'); eval-mode BN folded, ``relu(bn2(conv2(.)) + identity)`` in one epilogue."""
         y = conv3d_ndhwc(x, packed([self.conv1], self.norm1), relu=1)
-        idt = x if self.stride == 1 else conv3d_ndhwc(x, packed([self.downsample[0]], self.downsample[1]))
+        idt = x if self.stride == 1 else conv3d_ndhwc(x, packed([self.downsample[0]], self.downsample[1]), amax=False)
         return conv3d_ndhwc(y, packed([self.conv2], self.norm2), residual=idt, relu=1)
 
 

@@ -41,7 +41,7 @@ def map_features_2d_hip(features: Tensor, lin: torch.nn.Linear) -> Tensor:
     rows = f.permute(0, 2, 3, 1)
     if not rows.is_contiguous():
         rows = rows.contiguous()
-    return conv2d_nhwc(rows, packed_linear(lin)).permute(0, 3, 1, 2)
+    return conv2d_nhwc(rows, packed_linear(lin), amax=False).permute(0, 3, 1, 2)
 
 
 def scene_geometry(img_meta: dict, n_voxels, voxel_size, stride: int, device) -> Dict[str, Tensor]:
