@@ -246,7 +246,8 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
     nbytes = 4 * (x.numel() + pk["w"].numel() + out.numel() + (0 if residual is None else residual.numel()))
     arith = layer_arithmetic(k_iters)
     if ARITHMETIC == "f16x2" and pk.get("arith"):
-        arith = pk["arith"]            # training packs (conv_train.py) keep their bf16x3 planes: the weights change every step
+        arith = pk["arith"]            # pinned packs: training (conv_train.py: the weights change every step) and the point MLPs (packed_linear)
+        want_amax = False              # (a reader in the fp16-pair arithmetic takes its own pass, amax_of)
     if ARITHMETIC != "f16x2":
         planes = split_planes(pk)
         fn = lib.ndet_conv_ndhwc_bf16 if arith == "bf16" else lib.ndet_conv_ndhwc_split
@@ -354,8 +355,11 @@ def packed_linear(lin: nn.Linear, pad_in_to: int = 0):
         w = torch.cat([w, w.new_zeros(cout, width - cin)], dim=1)
     scale = torch.ones(cout, device=w.device) if lin.bias is not None else None
     shift = lin.bias.detach().float().contiguous() if lin.bias is not None else None
+    # arith: the point MLPs stay on bf16x3 under the fp16-pair mode.  Their inputs hold the reference's own garbage rows -- nerfdet.py:236-243 divides
+    # by (count + 1e-8), so a voxel no view sees carries ~1e9 where the seen ones carry O(1) -- and the fp16-pair scheme is exact only to
+    # 2^-40 of the TENSOR's maximum per element (its scale is per tensor): rows 2^-30 below the maximum would keep 10 bits.
     val = dict(w=w.unsqueeze(0).contiguous(), scale=scale, shift=shift, cout=cout, cin=width, ksize=1, stride=1, transposed=False,
-               kernel=(1, 1), strides=(1, 1), pads=(0, 0), ndim=2)
+               kernel=(1, 1), strides=(1, 1), pads=(0, 0), ndim=2, arith="bf16x3")
     store["linear"] = (stamp, val)
     return val
 

@@ -118,11 +118,11 @@ def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pa
         _lib.check(_lib.load().ndet_wgrad_dy_planes(c_void_p(g.data_ptr()), lo, cout, lrow, c_void_p(planes.data_ptr()),
                                                     c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "wgrad_dy_planes")
         pk = dict(w=planes, w_split=planes, scale=None, shift=None, cout=cout, cin=lrow, ksize=1, stride=1, transposed=False, kernel=(1, 1),
-                  strides=(1, 1), pads=(0, 0), ndim=2)
+                  strides=(1, 1), pads=(0, 0), ndim=2, arith="bf16x3")
     else:
         grows = _rows(g, (1, 1, 1), (1, 1, 1), (0, 0, 0), 0, 1, lrow)
         pk = dict(w=grows, scale=None, shift=None, cout=cout, cin=lrow, ksize=1, stride=1, transposed=False, kernel=(1, 1), strides=(1, 1),
-                  pads=(0, 0), ndim=2)
+                  pads=(0, 0), ndim=2, arith="bf16x3")
     if implicit is None:
         implicit = IMPLICIT_WGRAD and taps >= 9 and lo >= 16384
     if implicit and C.train_arithmetic() in ("bf16x3", "bf16") and cin % 64 == 0:
