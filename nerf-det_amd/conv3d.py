@@ -196,6 +196,15 @@ def split_planes(pk: dict) -> torch.Tensor:
     return planes
 
 
+def f16_weight_scale(wmax: float) -> float:
+    """The power of two that puts a weight tensor's largest magnitude in [2^14, 2^15) (below fp16's 65504, the low halves of everything within
+    2^-16 of it still normal); 1 for an all-zero / non-finite tensor, capped for denormal-sized weights."""
+    if not (wmax > 0.0 and math.isfinite(wmax)):
+        return 1.0
+    e = max(math.frexp(wmax)[1], -96)          # wmax = m 2^e, m in [1/2, 1)
+    return math.ldexp(1.0, 15 - e)
+
+
 def split_planes_f16(pk: dict):
     """(planes, 1 / scale): the packed weight times a power of two that puts max |w| in [2^14, 2^15), as two fp16 planes tiled per 32-channel K
     step, (taps, Cin/32, 2, Cout, 32) (built once per pack; reading max |w| back is the one host synchronisation, at pack time)."""
@@ -205,10 +214,7 @@ def split_planes_f16(pk: dict):
         taps, cout, cin = w.shape
         if cin % 32:
             raise ValueError(f"conv_ndhwc_arith: Cin={cin} must be a multiple of 32")
-        wmax = float(w.abs().max())
-        e = math.frexp(wmax)[1] if (wmax > 0.0 and math.isfinite(wmax)) else 15
-        e = max(e, -96)
-        scale = math.ldexp(1.0, 15 - e)
+        scale = f16_weight_scale(float(w.abs().max()))
         planes = torch.empty((taps, cin // 32, 2, cout, 32), dtype=torch.int16, device=w.device)
         st = c_void_p(torch.cuda.current_stream(w.device).cuda_stream)
         check(_lib.load().ndet_split_weights_f16x2(_ptr(w), taps, cout, cin, scale, _ptr(planes), st), "split_weights_f16x2")
