@@ -76,7 +76,7 @@ def test_pair_represents_an_operand_to_2_to_minus_22():
     err = np.abs((hi.astype(np.float64) + lo) / s - x)
     big = np.abs(x) >= np.abs(x).max() * 2.0 ** -16
     assert (err[big] <= 2.0 ** -22 * np.abs(x[big])).all()                      # two 11-bit halves (+ the sign of the low one)
-XX
+    assert (err <= np.maximum(2.0 ** -22 * np.abs(x), 2.0 ** -25 / s)).all()      # below that: half of fp16's subnormal spacing under the scale (<= 2^-39 max |x|)
 
 
 def _accumulate(planes, k):
