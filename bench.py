@@ -61,12 +61,33 @@ def k2_algorithmic_bytes(w, cm=32):
     return 4 * (w["n_views"] * 3 * h * wd + w["n_views"] * cm * (h // 4) * (wd // 4) + 2 * (3 + cm) * n)
 
 
-def traffic_of(traffic, name):
-    """Per-launch bytes of kernel ``name`` ("k_conv_split_halo<4,4>") in a {profile kernel name: bytes} table; the profile's names carry
-    every template argument ("k_conv_split_halo<4,4,0>"), so the match is on the name up to its closing bracket."""
+def profile_kernel_name(name, arithmetic):
+    """bench's span name ("k_conv_split_halo<4,4>/f16x2") -> the instantiation's name in a rocprofv3 profile ("k_conv_split_halo<4,4,1>"): the
+    last template argument of the split-family kernels is their arithmetic scheme (0 = bf16x3, 1 = fp16 pair, 2 = one bf16 product)."""
+    base = name[:-len("/f16x2")] if name.endswith("/f16x2") else name
+    sch = 1 if name.endswith("/f16x2") else (2 if arithmetic == "bf16" else 0)
+    if base == "k_conv_split_ws":
+        return f"k_conv_split_ws<{sch}>"
+    if base.startswith("k_conv_split_wsp<"):
+        args = base[len("k_conv_split_wsp<"):-1].split(",")
+        return f"k_conv_split_wsp<{sch},{args[0]},{args[1] if len(args) > 1 else 4}>"
+    if base.endswith(",p8>"):
+        return base[:-len(",p8>")] + f",{sch},8>"
+    if base.startswith("k_conv_split_halo<"):
+        return base[:-1] + f",{sch},4>"
+    if base.startswith(("k_conv_split<", "k_conv_split_chain<")):
+        return base[:-1] + f",{sch}>"
+    return base
+
+
+def traffic_of(traffic, name, arithmetic="bf16x3"):
+    """Per-launch bytes of kernel ``name`` in a {profile kernel name: bytes} table (rocprofv3 --pmc passes under profiles/)."""
+    want = profile_kernel_name(name, arithmetic)
+    if want in traffic:
+        return traffic[want]
     stem = name[:-1] if name.endswith(">") else name
-    return next((v for k, v in traffic.items() if k == name or k.startswith(stem + ",") or k.startswith(stem + "<") or k.startswith(stem + ">")
-                 or (not name.endswith(">") and k.startswith(stem + "_packed"))), None)    # K2 / K4 run as "<name>_packed<...>" at cm % 4 == 0
+    return next((v for k, v in traffic.items() if k == name or k.startswith(stem + "<") or k.startswith(stem + ">")
+                 or (not name.endswith(">") and k.startswith(stem + "_packed"))), None)    # K1 / K2 / K4 run as "<name><...>" / "<name>_packed<...>"
 
 
 def measured_traffic(workload):
@@ -360,12 +381,35 @@ def main():
         except Exception as e:     # the extra figure must never cost the headline line
             print(f"serve_in_flight skipped: {type(e).__name__}: {e}", file=sys.stderr)
 
+    six = None
+    if C3.ARITHMETIC == "f16x2" and not (args.graph or args.no_serving):
+        # the same K scenes in the six-product bf16x3 arithmetic (operands represented exactly), after the timed region: what the fp16-pair
+        # arithmetic is measured against
+        prev = C3.set_arithmetic("bf16x3")
+        try:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            ts = [time.perf_counter()]
+            for _ in range(args.steps):
+                step()
+                ts.append(time.perf_counter())
+            torch.cuda.synchronize()
+            per = sorted((b - a) * 1e3 for a, b in zip(ts, ts[1:]))
+            six = {"value": world * args.steps / (ts[-1] - ts[0]), "unit": "scenes/s", "median_ms": per[len(per) // 2],
+                   "note": "conv3d.set_arithmetic('bf16x3'): fp32 operands as exact 3-term bf16 sums, six MFMA products per multiply; same scenes, after the "
+                           "timed region; not the headline"}
+        except Exception as e:
+            print(f"bf16x3 comparison skipped: {type(e).__name__}: {e}", file=sys.stderr)
+        finally:
+            C3.set_arithmetic(prev)
+
     copy = hbm_copy_ceiling(device) if rank == 0 else None
     if rank == 0:
         spans = rec.span_ms()
         stages = rec.stage_ms()
         traffic, traffic_src = measured_traffic(args.workload)
-        conv_traffic = lambda name: traffic_of(traffic, name)
+        conv_traffic = lambda name: traffic_of(traffic, name, C3.ARITHMETIC)
         bf16x3 = C3.ARITHMETIC == "bf16x3"
         # MFMA products issued per algorithmic multiply-add by a launch of the split family: 3 in the fp16-pair arithmetic, 6 in bf16x3
         # (in f16x2 mode the layers below conv3d.F16_MIN_KSTEPS K steps run on bf16x3: their names carry no "/f16x2")
@@ -485,6 +529,8 @@ def main():
                 "value": serving * world, "unit": "scenes/s",
                 "note": "the same K scenes per GPU through nerfdet.forward_test_async with two scenes in flight on two streams (results collected "
                         "on the host one scene behind); not the headline -- `value` is the reference's one-scene-at-a-time test loop"}
+        if six is not None:
+            out["six_product_bf16x3_arithmetic"] = six
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, build_model(w), batch_cpu)
         print(json.dumps(out))

@@ -104,7 +104,7 @@ def amax_of(x: torch.Tensor) -> torch.Tensor:
 launch_hook = None  # bench.py: callable(flops, thunk, kernel_name) wrapping every MFMA-conv launch (event timing); None = direct
 
 KERNEL_NAMES = {("bf16x3", 64): "k_conv_split<64,64,2,2>", ("bf16x3", 128): "k_conv_split<128,128,2,2>", ("bf16x3", 12864): "k_conv_split<128,64,2,2>",
-                ("bf16x3", 128256): "k_conv_split_ws", ("bf16x3", 129256): "k_conv_split_wsp<128>", ("bf16x3", 129257): "k_conv_split_wsp<128,8>", ("bf16x3", 129064): "k_conv_split_wsp<64>", ("bf16x3", 3128): "k_conv_split_halo<4,2>", ("bf16x3", 3256): "k_conv_split_halo<8,2>", ("bf16x3", 3257): "k_conv_split_halo<4,4>",
+                ("bf16x3", 128256): "k_conv_split_ws", ("bf16x3", 129256): "k_conv_split_wsp<128>", ("bf16x3", 129257): "k_conv_split_wsp<128,8>", ("bf16x3", 129064): "k_conv_split_wsp<64>", ("bf16x3", 3128): "k_conv_split_halo<4,2>", ("bf16x3", 3256): "k_conv_split_halo<8,2>", ("bf16x3", 3257): "k_conv_split_halo<4,4>", ("bf16x3", 3258): "k_conv_split_halo<4,4,p8>",
                 ("f32", 64): "k_conv3d_igemm<64,64,2,2>", ("f32", 128): "k_conv3d_igemm<128,128,4,2>"}
 KERNEL_NAMES.update({("bf16x3", 100000 + t if t != 12864 else 112864): KERNEL_NAMES[("bf16x3", t)] for t in (64, 128, 12864)})   # direct-epilogue forms
 KERNEL_NAMES.update({("bf16", t): n for (a, t), n in list(KERNEL_NAMES.items()) if a == "bf16x3"})
@@ -145,7 +145,7 @@ def choose_tiling(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 
 
 def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: int = 0, transposed: bool = False, halo_ok: bool = False):
     """Tile (64 = 64x64, 128 = 128x128, 12864 = 128 rows x 64 channels, 128256 = wave-specialised 128 rows x 256 channels, 129256 / 129064 = its
-    persistent form with 128- / 64-row tiles, 3128 / 3256 / 3257 = halo-stationary 128-voxel patch x 128 / 256 channels) and split-K factor for the
+    persistent form with 128- / 64-row tiles, 3128 / 3256 / 3257 / 3258 = halo-stationary 128-voxel patch x 128 / 256 channels) and split-K factor for the
     bf16x3 kernel."""
     if tile == 0 and splits in (0, 1):     # splits == 1: the caller cannot split K (transposed, upsampled residual): the table's tile, unsplit
         key = (m, cout, k_iters, int(transposed))
@@ -169,7 +169,7 @@ def choose_tiling_split(m: int, cout: int, k_iters: int, tile: int = 0, splits: 
     if splits == 0:
         if transposed or tile in (100064, 100128, 112864):     # (the direct-epilogue forms of the unified tiles write final values: no split-K)
             return tile, 1
-        tm, tn = {12864: (128, 64), 128256: (128, 256), 129256: (128, 256), 129257: (128, 256), 129064: (64, 256), 3128: (128, 128), 3256: (128, 256), 3257: (128, 256)}.get(tile, (tile, tile))
+        tm, tn = {12864: (128, 64), 128256: (128, 256), 129256: (128, 256), 129257: (128, 256), 129064: (64, 256), 3128: (128, 128), 3256: (128, 256), 3257: (128, 256), 3258: (128, 256)}.get(tile, (tile, tile))
         tiles = ((m + tm - 1) // tm) * ((cout + tn - 1) // tn)
         splits = 1
         while splits < 32 and k_iters // (splits + 1) >= 24 and tiles * (splits + 1) <= 768:
@@ -233,7 +233,7 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
     halo_ok = (not transposed and all(s == 1 for s in stride) and all(k % 2 == 1 and q == k // 2 for k, q in zip(kernel, pad))
                and kernel[0] * kernel[1] * kernel[2] > 1)
     tile, splits = choose_tiling_split(m, pk["cout"], k_iters, tile, 1 if (transposed or residual_up2) else splits, transposed, halo_ok)
-    if tile in (3128, 3256, 3257):   # halo-stationary tiles: stride-1 same-padded multi-tap convolutions only, K split over the channel chunks
+    if tile in (3128, 3256, 3257, 3258):   # halo-stationary tiles: stride-1 same-padded multi-tap convolutions only, K split over the channel chunks
         if not halo_ok:
             tile = 128256 if pk["cout"] > 128 else 128
         else:

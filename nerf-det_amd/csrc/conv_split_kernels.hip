@@ -1425,18 +1425,22 @@ struct HaloRowMap {
 // one consumer wave per SIMD, <4,4>: 256 channels with two consumer waves per SIMD (each covers the other's LDS latency).
 // SCH 0: three bf16 planes, six products (fp32-class to 2^-24).  SCH 1: two fp16 planes, three products (see spl_split4_f16).
 // SCH 2: the leading bf16 plane only, one product (bf16 autocast arithmetic); the weights keep their three-plane layout.
-template <int NT16, int WGN, int SCH>
-__global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const Conv3dParams p, const uint16_t* __restrict__ wsplit, const HaloGeom g) {
+// NPROD: producer waves (4, or 8: an LDS-DMA piece holds its wave at the issue stage for ~250 cycles beside the MFMA stream, so the weight tile of a
+// 256-column step -- 32 pieces on two planes -- costs four producer waves 2 000 cycles where the step's MFMAs need 1 536; eight waves issue it in half)
+template <int NT16, int WGN, int SCH, int NPROD = 4>
+__global__ __launch_bounds__(64 * (2 * WGN + NPROD), 1) void k_conv_split_halo(const Conv3dParams p, const uint16_t* __restrict__ wsplit, const HaloGeom g) {
     constexpr int BN = 16 * NT16 * WGN;
-    constexpr int NCONS = 2 * WGN, NTHR = 64 * (NCONS + 4);
+    constexpr int NCONS = 2 * WGN, NTHR = 64 * (NCONS + NPROD);
+    constexpr int PT = 64 * NPROD;                          // producer threads
     constexpr int HALO_MAX = (BN == 128) ? 400 : 224;
     constexpr int NSTAGE = (BN == 128) ? 3 : 2;
-    constexpr int NPIECE = (HALO_MAX * 8 + 255) / 256;
+    constexpr int NPIECE = (HALO_MAX * 8 + PT - 1) / PT;
     constexpr int APL = HALO_MAX * CBK, BPL = BN * CBK;   // one plane, elements
     constexpr int NPL = SCH == 1 ? 2 : (SCH == 2 ? 1 : 3);   // operand planes staged and multiplied
     constexpr int WPL = SCH == 1 ? 2 : 3;                    // planes per K step in the weight tensor
     constexpr int BSTAGE = NPL * BPL;
-    constexpr int BR = BN / 64;                            // weight rows per producer thread and plane
+    constexpr int BR = BN / (16 * NPROD);                  // weight rows per producer thread and plane
+    static_assert(BR >= 1 && BN % (16 * NPROD) == 0, "every producer wave stages 16 rows of each row group");
     constexpr int NB = NPL * BR;                             // LDS-DMA instructions per producer thread and K step
     extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
     uint16_t* Bs = lds16 + NPL * APL;
@@ -1485,7 +1489,7 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
         unsigned avoff[NPIECE], adst[NPIECE], amask[NPIECE];   // amask bit k SET: looped depth tap k reads outside the grid
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) {
-            const int idx = stid + 256 * i;
+            const int idx = stid + PT * i;
             const int row = idx >> 3, q = idx & 7;
             const int hw = row % g.HW, hh = (row / g.HW) % g.HH, hd = row / (g.HW * g.HH);
             const int vd = d0 + hd - (dloop ? 0 : p.pd), vh = h0 - p.ph + hh, vw = w0 - p.pw + hw;
@@ -1499,12 +1503,12 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
             // rows past the halo are never read: their pieces are not stored (adst = ~0u)
             adst[i] = row < g.NH ? (unsigned)((row * CBK + (((q >> 1) ^ ws_swz(row)) * 8) + (q & 1) * 4) * 2) : ~0u;
         }
-        // weight tile by LDS-DMA: lane (row = stid >> 2 (+ 64 i), physical chunk = stid & 3) fetches logical chunk
+        // weight tile by LDS-DMA: lane (row = stid >> 2 (+ PT / 4 i), physical chunk = stid & 3) fetches logical chunk
         // physical ^ swizzle(row) of its row; the LDS image is lane-linear (1 KB per wave instruction)
         unsigned bvoff[BR];
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            const int row = (stid >> 2) + 64 * i, co = n0 + row;
+            const int row = (stid >> 2) + (PT / 4) * i, co = n0 + row;
             bvoff[i] = co < p.Cout ? (unsigned)((co * CBK + (((stid & 3) ^ ws_swz(row)) * 8)) * 2) : WS_OOB;
         }
         const unsigned wtile_b = (unsigned)p.Cout * CBK * 2;
@@ -1516,7 +1520,7 @@ __global__ __launch_bounds__(64 * (2 * WGN + 4), 1) void k_conv_split_halo(const
             for (int i = 0; i < BR; ++i)
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) {
-                    uint16_t* dst = stage + pl * BPL + (64 * i + pw4 * 16) * CBK;   // wave-uniform; the hardware adds lane * 16 B
+                    uint16_t* dst = stage + pl * BPL + ((PT / 4) * i + pw4 * 16) * CBK;   // wave-uniform; the hardware adds lane * 16 B
                     spl_dma16(bres, dst, bvoff[i], __builtin_amdgcn_readfirstlane(soff + pl * wtile_b));
                 }
             if (++dt == T) { dt = 0; ++dc; }
@@ -1684,7 +1688,7 @@ static bool halo_geometry(const Conv3dParams& p, int halo_max, HaloGeom& g) {
     return best < 1e29;
 }
 
-template <int NT16, int WGN, int SCH = 0>
+template <int NT16, int WGN, int SCH = 0, int NPROD = 4>
 static int split_launch_halo(const Conv3dParams& p, hipStream_t st, const char* fn) {
     constexpr int NPL = SCH == 1 ? 2 : (SCH == 2 ? 1 : 3);
     constexpr int BN = 16 * NT16 * WGN, HALO_MAX = (BN == 128) ? 400 : 224, NSTAGE = (BN == 128) ? 3 : 2;
@@ -1702,11 +1706,11 @@ static int split_launch_halo(const Conv3dParams& p, hipStream_t st, const char* 
     if (cs > lds) lds = cs;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_conv_split_halo<NT16, WGN, SCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_conv_split_halo<NT16, WGN, SCH, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv_split_halo<NT16, WGN, SCH>), grid, dim3(64 * (2 * WGN + 4)), lds, st, p, (const uint16_t*)p.w, g);
+    hipLaunchKernelGGL((k_conv_split_halo<NT16, WGN, SCH, NPROD>), grid, dim3(64 * (2 * WGN + NPROD)), lds, st, p, (const uint16_t*)p.w, g);
     return NDET_OK;
 }
 
@@ -1736,12 +1740,12 @@ static int split_launch_tile(const Conv3dParams& p, hipStream_t st, const char* 
         default: return split_launch_tile_sch<BM, BN, WGM, WGN, 0>(p, st, fn);
     }
 }
-template <int NT16, int WGN>
+template <int NT16, int WGN, int NPROD = 4>
 static int split_launch_halo_any(const Conv3dParams& p, hipStream_t st, const char* fn) {
     switch (conv_scheme(p)) {
-        case 1: return split_launch_halo<NT16, WGN, 1>(p, st, fn);
-        case 2: return split_launch_halo<NT16, WGN, 2>(p, st, fn);
-        default: return split_launch_halo<NT16, WGN, 0>(p, st, fn);
+        case 1: return split_launch_halo<NT16, WGN, 1, NPROD>(p, st, fn);
+        case 2: return split_launch_halo<NT16, WGN, 2, NPROD>(p, st, fn);
+        default: return split_launch_halo<NT16, WGN, 0, NPROD>(p, st, fn);
     }
 }
 
@@ -1759,7 +1763,7 @@ int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn)
     const int64_t big_tiles = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     if (tile == 0) tile = (big_tiles >= 192 && p.Cout >= 128) ? 128 : 64;
     {   // which operand is worth keeping in one XCD's L2 (Conv3dParams::order): the bytes its re-reads would otherwise fetch again
-        const int tm = tile == 64 ? 64 : 128, tn = tile == 64 || tile == 12864 ? 64 : (tile == 128 || tile == 3128 || tile == 4128 ? 128 : 256);
+        const int tm = tile == 64 ? 64 : 128, tn = tile == 64 || tile == 12864 ? 64 : (tile == 128 || tile == 3128 ? 128 : 256);
         const int64_t mt = (p.M + tm - 1) / tm, nt = (p.Cout + tn - 1) / tn;
         const int64_t taps = p.transposed ? 1 : (int64_t)p.kd * p.kh * p.kw;
         const int64_t w_bytes = taps * p.Cin * p.Cout * 6, a_bytes = (int64_t)p.M * p.Cin * 4 * (p.sd * p.sh * p.sw);
@@ -1783,6 +1787,10 @@ int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn)
         case 3128: rc = split_launch_halo_any<4, 2>(p, st, fn); break;
         case 3256: rc = split_launch_halo_any<8, 2>(p, st, fn); break;
         case 3257: rc = split_launch_halo_any<4, 4>(p, st, fn); break;
+        case 3258:                                                            // ... with eight producer waves (16 waves: 128 registers each --
+            rc = conv_scheme(p) == 1 ? split_launch_halo<4, 4, 1, 8>(p, st, fn)                  // the three-plane form does not fit and keeps four)
+                 : conv_scheme(p) == 2 ? split_launch_halo<4, 4, 2, 8>(p, st, fn) : split_launch_halo<4, 4, 0, 4>(p, st, fn);
+            break;
         default: ndet_set_error("%s: unknown tile %d", fn, tile); return NDET_E_INVALID;
     }
     if (rc != NDET_OK) return rc;
@@ -1955,7 +1963,7 @@ static int conv_split_entry(const char* fn, int max_order, const float* in_amax,
     NDET_REQUIRE(in && w_planes && out && kernel && stride && pad, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
     NDET_REQUIRE((scale == nullptr) == (shift == nullptr), NDET_E_INVALID, "%s: scale and shift go together", fn);
-    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128 || tile == 12864 || tile == 128256 || tile == 129256 || tile == 129257 || tile == 129064 || tile == 3128 || tile == 3256 || tile == 3257 ||
+    NDET_REQUIRE(relu >= 0 && relu <= 2 && (tile == 0 || tile == 64 || tile == 128 || tile == 12864 || tile == 128256 || tile == 129256 || tile == 129257 || tile == 129064 || tile == 3128 || tile == 3256 || tile == 3257 || tile == 3258 ||
                                           tile == 100064 || tile == 100128 || tile == 112864), NDET_E_INVALID, "%s: bad relu mode / tile", fn);
     NDET_REQUIRE(Cin % CBK == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
     NDET_REQUIRE((((uintptr_t)in | (uintptr_t)w_planes) & 15) == 0, NDET_E_UNSUPPORTED, "%s: in / weights must be 16-byte aligned", fn);

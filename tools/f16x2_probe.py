@@ -98,7 +98,7 @@ if __name__ == "__main__":
         run3d(256, 256, (6, 10, 12), 3, tile, 1, res=True)
         run3d(256, 512, (6, 10, 12), 1, tile, 2)
     # halo tiles
-    for tile in (3128, 3256, 3257):
+    for tile in (3128, 3256, 3257, 3258):
         run3d(256, 256, (8, 12, 12), 3, tile, 1, res=True)
         run3d(128, 256, (8, 12, 12), 3, tile, 2)
     # stride 2, magnitudes far from 1

@@ -52,7 +52,7 @@ def main():
         C3.set_arithmetic(sys.argv[1])
     if len(sys.argv) > 4:          # tune_conv2d.py <arithmetic> <n_views> <H> <W> [first]
         LAYERS = (first_block_layers if len(sys.argv) > 5 else layers_for)(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
-    tiles = (64, 128, 12864, 128256, 129256, 129257, 129064, 3128, 3256, 3257, 100064, 100128, 112864) if C3.ARITHMETIC in ("bf16x3", "bf16", "f16x2") else (64, 128)
+    tiles = (64, 128, 12864, 128256, 129256, 129257, 129064, 3128, 3256, 3257, 3258, 100064, 100128, 112864) if C3.ARITHMETIC in ("bf16x3", "bf16", "f16x2") else (64, 128)
     if os.environ.get("TUNE_TILES"):
         tiles = tuple(int(t) for t in os.environ["TUNE_TILES"].split(","))
     if os.environ.get("TUNE_LAYERS"):
