@@ -446,12 +446,23 @@ def main():
         conv_flops = sum(v[0] for v in by_kernel.values())
         conv_ms = sum(v[1] for v in by_kernel.values())
         conv_n = sum(v[2] for v in by_kernel.values())
-        dom_name, (dom_flops, dom_ms, dom_n, dom_bytes) = max(by_kernel.items(), key=lambda kv: kv[1][1])
+        # the dominant kernel: the kernel TEMPLATE (k_conv_split_halo, k_conv_split_ws, ...) with the largest share of the step in one arithmetic, its
+        # tile instantiations (<4,2>, <4,4>, <8,2>, <4,4,p8>: the same source, chosen per layer shape) taken together; they are listed one by one
+        # under roofline_all_convolutions.per_kernel
+        family = lambda name: name.split("<")[0] + ("/f16x2" if name.endswith("/f16x2") else "")
+        by_family = {}
+        for k, v in by_kernel.items():
+            f = by_family.setdefault(family(k), [0.0, 0.0, 0, 0.0, []])
+            for i in range(4):
+                f[i] += v[i]
+            f[4].append(k)
+        dom_name, (dom_flops, dom_ms, dom_n, dom_bytes, dom_members) = max(by_family.items(), key=lambda kv: kv[1][1])
         dom_tflops = dom_flops / (dom_ms * 1e-3) / 1e12
         dom_peak = all_peak = conv_peak
         if products is not None:      # per-launch product counts: the time the matrix cores need at their peak sets the roof
             dom_peak = MFMA_BF16_PEAK_TFLOPS / products(dom_name)
             all_peak = conv_flops / sum(v[0] * products(k) / MFMA_BF16_PEAK_TFLOPS for k, v in by_kernel.items())
+        dom_big = max(dom_members, key=lambda k: by_kernel[k][1])      # the instantiation the PMC traffic figure is quoted for
         mem = [(ms, i) for v in conv.values() for ms, i in v if i["flops"] / max(i["bytes"], 1) < ridge]
         mem_bytes, mem_ms = sum(i["bytes"] for _, i in mem), sum(ms for ms, _ in mem)
 
@@ -490,11 +501,12 @@ def main():
                                    f"{w['img_hw'][0]}x{w['img_hw'][1]}, {'x'.join(map(str, w['n_voxels']))} voxels, "
                                    f"{'bf16 convolutions' if C3.ARITHMETIC == 'bf16' else 'fp32'}, 1 scene/step/GPU, random-init weights",
                        "scenes_per_step": world, "parallelism": f"scene replicas x{world} (no data-path collective)"},
-            "roofline": {"kernel": f"{dom_name} (the convolution instantiation with the largest share of the step; event spans include the "
-                                   f"split-K reduce launch where a layer splits K)",
+            "roofline": {"kernel": f"{dom_name} (the convolution kernel with the largest share of the step, tile instantiations {sorted(dom_members)} "
+                                   f"together; event spans include the split-K reduce launch where a layer splits K; traffic: {dom_big})",
                          "bound": "mfma", "achieved": dom_tflops, "peak": dom_peak, "unit": "TFLOP/s",
-                         "frac": dom_tflops / dom_peak, "traffic": conv_traffic(dom_name),
-                         "traffic_source": None if conv_traffic(dom_name) is None else traffic_src, "peak_note": conv_peak_note,
+                         "frac": dom_tflops / dom_peak, "traffic": conv_traffic(dom_big),
+                         "traffic_source": None if conv_traffic(dom_big) is None else traffic_src, "peak_note": conv_peak_note,
+                         "traffic_launches_algorithmic_bytes": by_kernel[dom_big][3] / by_kernel[dom_big][2],
                          "algorithmic_flops_per_launch": dom_flops / dom_n, "algorithmic_bytes_per_launch": dom_bytes / dom_n,
                          "launches_per_step": dom_n / n_conv_steps,
                          "avg_launch_ms": dom_ms / dom_n, "total_ms_per_step": dom_ms / n_conv_steps, "sampled_steps": n_conv_steps},

@@ -56,7 +56,7 @@ def main():
     opt = build_optimizer(model)
     state = {"step": 0}
     # ~450 convolution launches per step (forward, data and weight gradients): their event pairs are sampled on every 4th timed step
-    rec = trace.Recorder(sample=lambda name: (not name.startswith(("k_conv", "f32:", "bf16x3:", "bf16:"))) or state["step"] % 4 == 0)
+    rec = trace.Recorder(sample=lambda name: (not name.startswith(("k_conv", "f32:", "bf16x3:", "bf16:", "f16x2:"))) or state["step"] % 4 == 0)
     for _ in range(args.warmup):
         out = train_one_step(model, data, opt)
     trace.recorder = rec
@@ -79,14 +79,15 @@ def main():
         pct = lambda q: per_step[min(len(per_step) - 1, int(round(q * (len(per_step) - 1))))]
         n_conv_steps = len([i for i in range(args.steps) if i % 4 == 0])
         spans = rec.span_ms()
-        arith = C3.ARITHMETIC
+        arith = C3.train_arithmetic()        # the fp16-pair mode trains on bf16x3 (its frozen, inference-form prefix runs "/f16x2" launches: 3 products)
         conv_peak = {"bf16x3": 2500.0 / 6.0, "bf16": 2500.0, "f32": 157.3}[arith]
-        peak_note = {"bf16x3": "dense bf16 MFMA peak 2500 TFLOP/s / 6 issued products per algorithmic multiply-add", "bf16": "dense bf16 MFMA peak",
-                     "f32": "dense fp32-input MFMA peak"}[arith]
+        peak_of = lambda name: 2500.0 / 3.0 if name.endswith("/f16x2") else conv_peak
+        peak_note = {"bf16x3": "dense bf16 MFMA peak 2500 TFLOP/s / 6 issued products per algorithmic multiply-add (3 for the fp16-pair launches of the "
+                               "frozen prefix)", "bf16": "dense bf16 MFMA peak", "f32": "dense fp32-input MFMA peak"}[arith]
         conv = {k: v for k, v in spans.items() if v and v[0][1].get("kind") == "conv"}
         by_kernel = {k: [sum(i["flops"] for _, i in v), sum(ms for ms, _ in v), len(v)] for k, v in conv.items()}
         line = dict(metric="training steps/sec (cfg3 shapes)", value=world / dt, unit="scenes/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                    ms_per_step=dt * 1e3, median_ms=pct(0.5), p10_ms=pct(0.1), p90_ms=pct(0.9), higher_is_better=True, scaling="weak", dtype=arith,
+                    ms_per_step=dt * 1e3, median_ms=pct(0.5), p10_ms=pct(0.1), p90_ms=pct(0.9), higher_is_better=True, scaling="weak", dtype=arith + (" (frozen prefix: f16x2)" if C3.ARITHMETIC == "f16x2" else ""),
                     data="synthetic",
                     config=dict(workload=f"cfg3 shapes, {world} GPU(s) x 1 scene/step, {arith} convolutions: {args.views} source views 240x320 + 10 NeRF target "
                                          f"views, 40x40x16 voxels, 2048 rays x 64 samples, {'5' if args.depth_supervise else '4'} losses + backward + clip + AdamW"
@@ -96,12 +97,13 @@ def main():
             dom, (df, dms, dn) = max(by_kernel.items(), key=lambda kv: kv[1][1])
             tf = df / (dms * 1e-3) / 1e12
             line["roofline"] = dict(kernel=f"{dom} (the convolution instantiation with the largest share of the training step: forward, data-gradient and "
-                                           f"weight-gradient launches all run on it)", bound="mfma", achieved=tf, peak=conv_peak, unit="TFLOP/s", frac=tf / conv_peak,
+                                           f"weight-gradient launches all run on it)", bound="mfma", achieved=tf, peak=peak_of(dom), unit="TFLOP/s", frac=tf / peak_of(dom),
                                     traffic=None, peak_note=peak_note, launches_per_step=dn / n_conv_steps, avg_launch_ms=dms / dn,
                                     total_ms_per_step=dms / n_conv_steps, sampled_steps=n_conv_steps)
             cf, cms, cn = (sum(v[i] for v in by_kernel.values()) for i in range(3))
-            line["roofline_all_convolutions"] = dict(bound="mfma", achieved=cf / (cms * 1e-3) / 1e12, peak=conv_peak, unit="TFLOP/s",
-                                                     frac=cf / (cms * 1e-3) / 1e12 / conv_peak, launches_per_step=cn / n_conv_steps,
+            all_peak = cf / sum(v[0] / peak_of(k) for k, v in by_kernel.items())      # FLOP-weighted harmonic mean of the launches' peaks
+            line["roofline_all_convolutions"] = dict(bound="mfma", achieved=cf / (cms * 1e-3) / 1e12, peak=all_peak, unit="TFLOP/s",
+                                                     frac=cf / (cms * 1e-3) / 1e12 / all_peak, launches_per_step=cn / n_conv_steps,
                                                      total_ms_per_step=cms / n_conv_steps, algorithmic_flops_per_step=cf / n_conv_steps,
                                                      per_kernel={k: dict(launches_per_step=v[2] / n_conv_steps, avg_launch_ms=v[1] / v[2],
                                                                          tflops=v[0] / (v[1] * 1e-3) / 1e12) for k, v in sorted(by_kernel.items())})
