@@ -12,6 +12,9 @@ if len(sys.argv) > 2 and sys.argv[2] == "nochain":     # layer_times.py cfg2 noc
 if len(sys.argv) > 2 and sys.argv[2] in ("f16x2", "bf16x3", "bf16", "f32"):     # layer_times.py cfg2 f16x2
     from nerfdet_amd import conv3d
     conv3d.set_arithmetic(sys.argv[2])
+if os.environ.get("F16_MIN_KSTEPS"):
+    from nerfdet_amd import conv3d
+    conv3d.F16_MIN_KSTEPS = int(os.environ["F16_MIN_KSTEPS"])
 dev = torch.device("cuda")
 det = bench.build_model(w).to(dev)
 batch = bench.to_device(bench.synth_batch(w, 0), dev)
