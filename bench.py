@@ -85,6 +85,8 @@ def traffic_of(traffic, name, arithmetic="bf16x3"):
     want = profile_kernel_name(name, arithmetic)
     if want in traffic:
         return traffic[want]
+    if want.startswith("k_conv_split_halo<") and want.endswith(",4>") and want[:-len(",4>")] + ">" in traffic:
+        return traffic[want[:-len(",4>")] + ">"]          # profiles older than the producer-count template argument
     stem = name[:-1] if name.endswith(">") else name
     return next((v for k, v in traffic.items() if k == name or k.startswith(stem + "<") or k.startswith(stem + ">")
                  or (not name.endswith(">") and k.startswith(stem + "_packed"))), None)    # K1 / K2 / K4 run as "<name><...>" / "<name>_packed<...>"

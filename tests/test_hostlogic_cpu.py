@@ -46,9 +46,15 @@ def test_bench_bookkeeping():
     traffic, src = bench.measured_traffic("cfg2")
     assert traffic["k_backproject_aggregate"] > bench.k1_algorithmic_bytes(w) and src.startswith("profiles/")
     # the bench names kernels without the trailing template arguments the profile carries: the dominant convolution must be found
-    assert bench.traffic_of(traffic, "k_conv_split_halo<4,4>") > 0 and bench.traffic_of(traffic, "k_density_features_packed") > 0
+    # span names -> the profile's instantiation names (the arithmetic scheme is the split-family kernels' last-but-one template argument)
+    assert bench.profile_kernel_name("k_conv_split_halo<4,4>/f16x2", "f16x2") == "k_conv_split_halo<4,4,1,4>"
+    assert bench.profile_kernel_name("k_conv_split_halo<4,4,p8>/f16x2", "f16x2") == "k_conv_split_halo<4,4,1,8>"
+    assert bench.profile_kernel_name("k_conv_split_ws", "bf16x3") == "k_conv_split_ws<0>" and bench.profile_kernel_name("k_conv_split_wsp<64>", "bf16") == "k_conv_split_wsp<2,64,4>"
+    assert bench.profile_kernel_name("k_conv_split_chain<64>/f16x2", "f16x2") == "k_conv_split_chain<64,1>"
+    assert bench.traffic_of(traffic, "k_conv_split_halo<4,4>/f16x2", "f16x2") > 0 and bench.traffic_of(traffic, "k_density_features_packed") > 0
     assert bench.traffic_of({"k_conv_split_halo<4,4,0>": 7, "k_conv_split_halo<4,2,0>": 9}, "k_conv_split_halo<4,2>") == 9
-    assert bench.traffic_of({"k_conv_split<64,64,2,2,false>": 5}, "k_conv_split<64,64,2,2>") == 5 and bench.traffic_of({}, "k_x") is None
+    assert bench.traffic_of({"k_conv_split<64,64,2,2,0>": 5, "k_conv_split<64,64,2,2,1>": 6}, "k_conv_split<64,64,2,2>/f16x2", "f16x2") == 6
+    assert bench.traffic_of({}, "k_x") is None
     # BASELINE.json configs[4] as stated: ResNet-101, 101 views 320x480, 80x80x32 voxels
     w5 = bench.WORKLOADS["cfg5"]
     assert (w5["n_views"], w5["img_hw"], w5["n_voxels"], w5["depth"]) == (101, (320, 480), (80, 80, 32), 101)

@@ -1,10 +1,10 @@
-"""scratch: one conv3d_ndhwc shape a few times (for rocprofv3 --pmc passes).  argv: cin cout X Y Z k tile splits"""
+"""scratch: one conv3d_ndhwc shape a few times (for rocprofv3 --pmc passes).  argv: cin cout X Y Z k tile splits [arithmetic]"""
 import os, sys, torch
 from torch import nn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerfdet_amd import conv3d as C3
 cin, cout, X, Y, Z, k, tile, splits = (int(v) for v in sys.argv[1:9])
-C3.set_arithmetic("bf16x3")
+C3.set_arithmetic(sys.argv[9] if len(sys.argv) > 9 else "bf16x3")
 dev = torch.device("cuda")
 conv = nn.Conv3d(cin, cout, k, 1, k // 2, bias=False).to(dev); bn = nn.BatchNorm3d(cout).to(dev).eval()
 pk = C3.packed([conv], bn)
