@@ -75,11 +75,18 @@ AMAX = _AmaxSlots()
 amax_fallbacks = 0      # how many inputs needed their own ndet_amax_f32 pass (diagnostic: the hot path should carry the attribute)
 
 
+def _tag_amax(t: torch.Tensor, slot: torch.Tensor) -> None:
+    """Attach the slot together with the tensor's version counter: an in-place write to the tensor (or to a view of it) afterwards makes the
+    slot stale, and a stale maximum could overflow fp16 -- amax_of then takes a fresh pass instead of trusting it."""
+    t._ndet_amax = slot
+    t._ndet_amax_version = t._version
+
+
 def carry_amax(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
-    """``dst`` is a view / permutation of ``src`` (same elements): it inherits the max |x| slot."""
+    """``dst`` is a view / permutation / contiguous copy of ``src`` (same elements): it inherits the max |x| slot."""
     slot = getattr(src, "_ndet_amax", None)
-    if slot is not None:
-        dst._ndet_amax = slot
+    if slot is not None and getattr(src, "_ndet_amax_version", None) == src._version:
+        _tag_amax(dst, slot)
     return dst
 
 
@@ -92,12 +99,12 @@ def amax_of(x: torch.Tensor) -> torch.Tensor:
     """The device slot holding max |x| of ``x``: left by the kernel that wrote it, or computed here in one pass."""
     global amax_fallbacks
     slot = getattr(x, "_ndet_amax", None)
-    if slot is None:
+    if slot is None or getattr(x, "_ndet_amax_version", None) != x._version:
         amax_fallbacks += 1
         slot = AMAX.take(x.device)
         st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         check(_lib.load().ndet_amax_f32(_ptr(x), x.numel(), _ptr(slot), st), "amax_f32")
-        x._ndet_amax = slot
+        _tag_amax(x, slot)
     return slot
 
 
@@ -273,7 +280,7 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
                                                            splits, tile, 1 if arith == "f16x2" else 0, _ptr(in_amax), winv, _ptr(out_amax), _ptr(ws), st),
                                  "conv_ndhwc_arith"), arith, tile, nbytes)
     if want_amax:
-        out._ndet_amax = out_amax
+        _tag_amax(out, out_amax)
     return out
 
 
@@ -488,7 +495,7 @@ def conv2d_chain_nhwc(x: torch.Tensor, pk: dict, pk3: dict, residual: Optional[t
         thunk = lambda: check(lib.ndet_conv_chain_arith(_ptr(x), _ptr(p1), n, h, w, cin, mid, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw), _ptr(pk["scale"]),
                                                         _ptr(pk["shift"]), _ptr(p3), cout, _ptr(pk3["scale"]), _ptr(pk3["shift"]), _ptr(residual), relu,
                                                         _ptr(out), 1, _ptr(in_amax), w1inv, w3inv, _ptr(out_amax), st), "conv_chain_arith")
-        out._ndet_amax = out_amax
+        _tag_amax(out, out_amax)
     else:
         p1, p3 = split_planes(pk), split_planes(pk3)
         thunk = lambda: check(lib.ndet_conv_chain_split(_ptr(x), _ptr(p1), n, h, w, cin, mid, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw), _ptr(pk["scale"]),

@@ -139,7 +139,19 @@ def test_f16x2_input_without_a_slot_takes_its_own_pass(device):
         assert C.amax_fallbacks == before + 1 and C.amax_value(xd._ndet_amax) == float(x.abs().max())
         y2 = _run(C, "f16x2", xd, pk, None, 1, device)           # the slot is remembered on the tensor
         assert C.amax_fallbacks == before + 1
-    assert torch.equal(y1, y2)
+        assert torch.equal(y1, y2)
+        # an in-place write makes the remembered maximum stale (here it would overflow fp16: x grows 2^20-fold): a fresh pass is taken
+        xd.mul_(2.0 ** 20)
+        y3 = _run(C, "f16x2", xd, pk, None, 1, device)
+        assert C.amax_fallbacks == before + 2 and C.amax_value(xd._ndet_amax) == float(xd.abs().max())
+        assert torch.isfinite(y3).all()
+        # ... also through a view the package made of it
+        y4 = _run(C, "f16x2", y3, pk2 := C.packed([torch.nn.Conv3d(128, 64, 1, bias=False).to(device)]), None, 0, device)
+        v = C.carry_amax(y3, y3.view(-1, 128).view(y3.shape))
+        y3.add_(1.0e3)
+        fb = C.amax_fallbacks
+        y5 = _run(C, "f16x2", v, pk2, None, 0, device)
+        assert C.amax_fallbacks == fb + 1 and torch.isfinite(y5).all() and not torch.equal(y4, y5)
 
 
 @pytest.mark.parametrize("cin,mid,cout,use_res", [(64, 64, 256, True), (128, 128, 512, True), (64, 64, 256, False)])
