@@ -269,11 +269,12 @@ __device__ __forceinline__ void conv_split_mainloop(const Conv3dParams& p, const
         for (int ks = 0; ks < CBK / 16; ++ks) {
             bf16x8 fa[NPL][MT], fb[NPL][NT];
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
+            for (int pl = 0; pl < NPL; ++pl) {      // in the order the products below need them: (A plane k, B plane NPL-1-k) first -- the first MFMA
+                const int pq = NPL - 1 - pl;        // then waits for 2 of the 2 NPL plane reads instead of all of them (LDS returns in order)
 #pragma unroll
                 for (int t = 0; t < MT; ++t) fa[pl][t] = *reinterpret_cast<const bf16x8*>(abase + pl * APL + t * 32 * SPL_RS + ks * 16);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) fb[pl][t] = *reinterpret_cast<const bf16x8*>(bbase + pl * BPL + t * 32 * SPL_RS + ks * 16);
+                for (int t = 0; t < NT; ++t) fb[pq][t] = *reinterpret_cast<const bf16x8*>(bbase + pq * BPL + t * 32 * SPL_RS + ks * 16);
             }
             // smallest terms first; the (pa, pb) pairs with pa + pb <= 2
 #pragma unroll
@@ -993,11 +994,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
                 const uint16_t* st = lds16 + (j & 1) * STAGE;
                 bf16x8 fa[NPL][4], fb[NPL][8];
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) {
+                for (int pl = 0; pl < NPL; ++pl) {      // (A plane k, B plane NPL-1-k): the operands of the first products first
+                    const int pq = NPL - 1 - pl;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) fa[pl][t] = *reinterpret_cast<const bf16x8*>(st + aoff + pl * APL + t * 16 * CBK);
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) fb[pl][t] = *reinterpret_cast<const bf16x8*>(st + boff + pl * BPL + t * 16 * CBK);
+                    for (int t = 0; t < 8; ++t) fb[pq][t] = *reinterpret_cast<const bf16x8*>(st + boff + pq * BPL + t * 16 * CBK);
                 }
 #pragma unroll
                 for (int order = NPL - 1; order >= 0; --order)
@@ -1275,11 +1277,12 @@ __global__ __launch_bounds__(64 * (NCONS + 4), 1) void k_conv_split_wsp(const Co
                     const uint16_t* st = lds16 + (j & 1) * STAGE;
                     bf16x8 fa[NPL][4], fb[NPL][NTB];
 #pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl) {
+                    for (int pl = 0; pl < NPL; ++pl) {      // (A plane k, B plane NPL-1-k): the operands of the first products first
+                        const int pq = NPL - 1 - pl;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) fa[pl][t] = *reinterpret_cast<const bf16x8*>(st + aoff + pl * APL + t * 16 * CBK);
 #pragma unroll
-                        for (int t = 0; t < NTB; ++t) fb[pl][t] = *reinterpret_cast<const bf16x8*>(st + boff + pl * BPL + t * 16 * CBK);
+                        for (int t = 0; t < NTB; ++t) fb[pq][t] = *reinterpret_cast<const bf16x8*>(st + boff + pq * BPL + t * 16 * CBK);
                     }
 #pragma unroll
                     for (int order = NPL - 1; order >= 0; --order)
@@ -1609,17 +1612,20 @@ __global__ __launch_bounds__(64 * (2 * WGN + NPROD), 1) void k_conv_split_halo(c
                 const int tapoff = (kd * g.HH + kh) * g.HW + kw;
                 const uint16_t* bst = Bs + (s % NSTAGE) * BSTAGE + boff;
                 bf16x8 fa[NPL][4], fb[NPL][NT16];
+                const uint16_t* ap[4];
 #pragma unroll
                 for (int ta = 0; ta < 4; ++ta) {
                     const int hr = hr0[ta] + tapoff;
-                    const uint16_t* ap = lds16 + hr * CBK + ((fc ^ ws_swz(hr)) * 8);
-#pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl) fa[pl][ta] = *reinterpret_cast<const bf16x8*>(ap + pl * APL);
+                    ap[ta] = lds16 + hr * CBK + ((fc ^ ws_swz(hr)) * 8);
                 }
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl)
+                for (int pl = 0; pl < NPL; ++pl) {      // (A plane k, B plane NPL-1-k): the operands of the first products first -- LDS returns in
+                    const int pq = NPL - 1 - pl;        // order, so the first MFMA then waits for a third / half of the reads instead of all of them
 #pragma unroll
-                    for (int tb = 0; tb < NT16; ++tb) fb[pl][tb] = *reinterpret_cast<const bf16x8*>(bst + pl * BPL + tb * 16 * CBK);
+                    for (int ta = 0; ta < 4; ++ta) fa[pl][ta] = *reinterpret_cast<const bf16x8*>(ap[ta] + pl * APL);
+#pragma unroll
+                    for (int tb = 0; tb < NT16; ++tb) fb[pq][tb] = *reinterpret_cast<const bf16x8*>(bst + pq * BPL + tb * 16 * CBK);
+                }
 #pragma unroll
                 for (int order = NPL - 1; order >= 0; --order)
                     if (order <= p.max_order)

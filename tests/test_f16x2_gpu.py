@@ -122,7 +122,7 @@ def test_f16x2_dynamic_range_limit_is_what_the_header_says(device):
     assert rel(0) < 1e-6 and rel(1) < 1e-6, (rel(0), rel(1))              # within 2^-12 of the maximum: full precision
     amax = float(x.abs().max())
     abs_err = float((y[2:] - ref[2:]).abs().max())
-    assert abs_err <= 128 * 2.0 ** -38 * amax * float(lin.weight.abs().max()), (abs_err, amax)    # K x |w| x 2^-40 amax, with margin
+    assert abs_err <= 128 * 2.0 ** -38 * amax * float(lin.weight.detach().abs().max()), (abs_err, amax)    # K x |w| x 2^-40 amax, with margin
     assert 1e-5 < rel(2) < 1e-2, rel(2)                                    # ... which is ~10 bits for rows 2^-30 below it
 
 
