@@ -36,6 +36,7 @@ struct Conv3dParams {
     // they are split, by the scale the kernel derives from `amax_in`; the epilogue multiplies the accumulators by the inverse of both.
     const float* amax_in = nullptr;   // device: the input tensor's amax slot (8 per-XCD sub-slots, see conv_amax_read below)
     float winv = 1.0f;                // 1 / (weight scale)
+    int nt = 0;                       // 1: the output is written with non-temporal stores (set by the launcher for outputs that cannot stay in the caches)
     float* amax_out = nullptr;        // any arithmetic, optional: max |out| is atomically maxed into the slot at amax_out (1 KiB, zeroed by the caller
                                       // before the launch) -- the next layer's amax_in without another pass over the tensor
 };
@@ -161,7 +162,11 @@ __device__ __forceinline__ void conv_store_rows_mapped(const Conv3dParams& p, co
                 if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             }
-            *reinterpret_cast<float4*>(dst + orow * p.Cout + co) = v;
+            if (p.nt) {
+                typedef float f32x4nt __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store((f32x4nt){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4nt*>(dst + orow * p.Cout + co));
+            }
+            else *reinterpret_cast<float4*>(dst + orow * p.Cout + co) = v;
         }
     } else {  // Cout not a multiple of 4 (the fused head conv, Cout = 25): scalar columns
         for (int idx = tid; idx < rows * BN; idx += NTHR) {

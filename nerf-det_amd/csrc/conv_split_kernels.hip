@@ -342,7 +342,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
                     if (p.relu == 2) v = fmaxf(v, 0.f);
                     v += rr[r];
                     if (p.relu == 1) v = fmaxf(v, 0.f);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, vo, so, 0);
+                    if (p.nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, vo, so, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, vo, so, 0);
                     if (mrow + (r & 3) + 8 * (r >> 2) < p.M) mx = fmaxf(mx, fabsf(v));      // rows past M: dropped stores of values that are not the layer's
                 }
             }
@@ -537,7 +538,8 @@ __global__ __launch_bounds__(256, MID == 64 ? (SCH == 1 ? CHAIN64_F16_WGS : 3) :
                     if (c.relu3 == 2) v = fmaxf(v, 0.f);
                     v += rr[r];
                     if (c.relu3 == 1) v = fmaxf(v, 0.f);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, vo, so, 0);
+                    if (p.nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, vo, so, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, vo, so, 0);
                     if (m0 + h * RH + 4 * (lane >> 5) + rt * 32 + (r & 3) + 8 * (r >> 2) < p.M) omax = fmaxf(omax, fabsf(v));
                 }
             };
@@ -1761,8 +1763,18 @@ static int split_launch_halo_any(const Conv3dParams& p, hipStream_t st, const ch
 #ifndef NDET_ORDER_DEFAULT
 #define NDET_ORDER_DEFAULT -1      // -1: chosen per launch below; 0 / 1 force one order (measurement builds)
 #endif
+// Outputs of 32 MB and more (eight L2s of 4 MB: nothing of them is re-read from a cache) are written with non-temporal stores: the float4 copy
+// kernel of bench.py reaches 6.5 TB/s with them and 5.4 without, and the HBM-bound layers gain 3 - 12 % (l1.conv1 86 -> 75 us; the step 0.05 ms).
+// NDET_NT_BYTES in the environment moves the threshold (measurement runs).
+static int64_t conv_nt_bytes() {
+    static int64_t v = -1;
+    if (v < 0) { const char* e = getenv("NDET_NT_BYTES"); v = e ? atoll(e) : ((int64_t)32 << 20); }
+    return v;
+}
+
 int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn) {
     p.direct = 0;
+    p.nt = (p.splits <= 1 || p.transposed) && (int64_t)p.M * p.Cout * 4 * (p.transposed ? 8 : 1) >= conv_nt_bytes() ? 1 : 0;
     if (tile >= 100000 && (tile - 100000 == 64 || tile - 100000 == 128 || tile - 100000 == 12864)) {   // 100064 / 100128 / 112864: direct epilogue
         tile -= 100000;
         NDET_REQUIRE(!p.transposed && p.splits == 1 && !p.res_up2 && p.Cout % 32 == 0 && ((int64_t)p.M + 128) * p.Cout * 4 < ((int64_t)1 << 32),
@@ -2087,6 +2099,7 @@ extern "C" int ndet_conv_chain_arith(const float* in, const uint16_t* w_planes, 
     ConvChain c;
     c.w3 = w3_planes; c.scale3 = scale3; c.shift3 = shift3; c.res = residual; c.out = out; c.Cout3 = Cout; c.relu3 = relu3;
     c.w3inv = arith == 1 ? w3_inv_scale : 1.0f; c.amax_out = out_amax;
+    p.nt = (int64_t)p.M * Cout * 4 >= conv_nt_bytes() ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (Cmid == 64) rc = arith == 2 ? chain_launch<64, 2>(p, c, st, fn) : (arith == 1 ? chain_launch<64, 1>(p, c, st, fn) : chain_launch<64, 0>(p, c, st, fn));
