@@ -507,6 +507,7 @@ def main():
                                    f"together; event spans include the split-K reduce launch where a layer splits K; traffic: {dom_big})",
                          "bound": "mfma", "achieved": dom_tflops, "peak": dom_peak, "unit": "TFLOP/s",
                          "frac": dom_tflops / dom_peak, "traffic": conv_traffic(dom_big),
+                         "achieved_over_six_product_roof": dom_tflops / (MFMA_BF16_PEAK_TFLOPS / 6.0),   # the roof of the bf16x3 arithmetic (rounds 1 - 3a)
                          "traffic_source": None if conv_traffic(dom_big) is None else traffic_src, "peak_note": conv_peak_note,
                          "traffic_launches_algorithmic_bytes": by_kernel[dom_big][3] / by_kernel[dom_big][2],
                          "algorithmic_flops_per_launch": dom_flops / dom_n, "algorithmic_bytes_per_launch": dom_bytes / dom_n,
