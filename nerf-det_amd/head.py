@@ -14,7 +14,7 @@ from torch import nn
 
 from . import losses  # noqa: F401  (registers the loss types the head builds)
 from . import ops
-from .conv3d import conv3d_ndhwc, packed, to_ndhwc
+from .conv3d import carry_amax, conv3d_ndhwc, packed, to_ndhwc
 from .nms import aligned_3d_nms
 from .registry import HEADS, build_loss
 
@@ -83,7 +83,8 @@ class ScanNetImVoxelHeadV2(nn.Module):
         epilogue shift), then channel views.  imvoxel_head_v2.py:444-449."""
         pk = packed([self.centerness_conv, self.reg_conv, self.cls_conv])
         n_reg = self.reg_conv.out_channels
-        outs = [conv3d_ndhwc(to_ndhwc(x[b].float()), pk, amax=False).permute(3, 0, 1, 2) for b in range(x.shape[0])]
+        one = x.shape[0] == 1      # a batch of one: x[0] holds the same elements as x (the fp16-pair arithmetic's maximum carries over)
+        outs = [conv3d_ndhwc(to_ndhwc(carry_amax(x, x[b]) if one else x[b].float()), pk, amax=False).permute(3, 0, 1, 2) for b in range(x.shape[0])]
         o = outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
         return o[:, :1], torch.exp(scale(o[:, 1:1 + n_reg])), o[:, 1 + n_reg:]
 
@@ -180,7 +181,7 @@ class ScanNetImVoxelHeadV2(nn.Module):
         v0 = valid.reshape(gx0, gy0, gz0).float().contiguous()
         bests, labels, boxes = [], [], []
         for i, (f, sc) in enumerate(zip(x, self.scales)):
-            raw = conv3d_ndhwc(to_ndhwc(f[0].float()), pk, amax=False)  # (X,Y,Z,25)
+            raw = conv3d_ndhwc(to_ndhwc(carry_amax(f, f[0]) if f.dtype == torch.float32 else f[0].float()), pk, amax=False)  # (X,Y,Z,25)
             gx, gy, gz = raw.shape[:3]
             n = gx * gy * gz
             fac = gx0 // gx

@@ -10,7 +10,7 @@ import torch
 from torch import nn
 import torch.nn.functional as F
 
-from .conv3d import conv3d_ndhwc, packed, to_ndhwc
+from .conv3d import carry_amax, conv3d_ndhwc, packed, to_ndhwc
 from .conv_train import conv_forward
 from .registry import NECKS
 
@@ -121,8 +121,10 @@ class FastIndoorImVoxelNeck(nn.Module):
                     # x = down_outs[i] + up(x): ReLU first, then the skip add (imvoxelnet.py:30-31)
                     t = conv3d_ndhwc(t, packed([up[3]], up[4]), residual=downs[i], relu=2)
                 ob = getattr(self, f"out_block_{i}")
-                per_level[i].append(conv3d_ndhwc(t, packed([ob[0]], ob[1]), relu=1).permute(3, 0, 1, 2))
-        return [lv[0].unsqueeze(0) if len(lv) == 1 else torch.stack(lv) for lv in per_level]
+                o = conv3d_ndhwc(t, packed([ob[0]], ob[1]), relu=1)
+                per_level[i].append(carry_amax(o, o.permute(3, 0, 1, 2)))
+        # (one scene: the views keep the maximum the convolution left behind, so the head's first launch needs no pass of its own)
+        return [carry_amax(lv[0], lv[0].unsqueeze(0)) if len(lv) == 1 else torch.stack(lv) for lv in per_level]
 
     def forward_library(self, x):
         downs = []
