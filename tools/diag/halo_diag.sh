@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU box: the fp16-pair halo tiles with one ingredient of the K step removed at a time (diagnostic builds: wrong results, same instruction
+# The three libdiag_*.so are builds of csrc with tools/diag/halo_diag.patch applied and -DHALO_DIAG_NO_DMA / _NO_BARRIER / _NO_READS (one each), linked like the Makefile links libnerfdet_hip.so.
 # streams otherwise): which one sets the step?  libdiag_NO_DMA: the producers issue no weight DMA after the prologue; libdiag_NO_BARRIER: no
 # per-step barrier on either side; libdiag_NO_READS: the consumers multiply stale registers (no fragment reads after step 0).
 L=nerf-det_amd/lib
