@@ -151,7 +151,7 @@ class ResNet(nn.Module):
         library modules."""
         outs = []
         with torch.no_grad():
-            y = self._stem(x)
+            y = self._stem(x, training=True)
             for i in range(self.frozen_stages):
                 for blk in getattr(self, f"layer{i + 1}"):
                     y = blk.forward_nhwc(y)
@@ -164,10 +164,12 @@ class ResNet(nn.Module):
                 outs.append(y)
         return tuple(outs)
 
-    def _stem(self, x):
+    def _stem(self, x, training: bool = False):
         """conv1 + bn1 (eval) + ReLU + max-pool -> (N,H/4,W/4,64) channels-last: one launch (csrc/stem_kernels.hip); with the exact
-        fp32-MFMA arithmetic selected, the vendor library's convolution followed by the fused BN + ReLU + pool pass."""
-        if stem_ok(self.conv1, self.bn1, x):
+        fp32-MFMA arithmetic selected, the vendor library's convolution followed by the fused BN + ReLU + pool pass.  (The bf16 training
+        step keeps the library stem it was validated with: tests/test_train_gpu.py's bf16 gradient bands were measured on it.)"""
+        from . import conv3d as _c
+        if stem_ok(self.conv1, self.bn1, x) and not (training and _c.ARITHMETIC == "bf16"):
             return stem_conv_bn_relu_maxpool(x, self.conv1, self.bn1)
         return bn_relu_maxpool_nhwc(_nhwc(self.conv1(x.contiguous(memory_format=torch.channels_last))), self.bn1)
 

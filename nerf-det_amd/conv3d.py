@@ -522,7 +522,8 @@ def bn_relu_maxpool_nhwc(x: torch.Tensor, bn: nn.BatchNorm2d) -> torch.Tensor:
 def stem_ok(conv: nn.Module, bn: nn.Module, x: torch.Tensor) -> bool:
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and isinstance(conv, nn.Conv2d) and conv.in_channels == 3 and conv.out_channels == 64
             and tuple(conv.kernel_size) == (7, 7) and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (3, 3) and conv.bias is None
-            and not bn.training and ARITHMETIC in ("bf16x3", "f16x2") and min(x.shape[2:]) >= 7)
+            and not bn.training and ARITHMETIC in SPLIT_FAMILY and min(x.shape[2:]) >= 7)      # (bf16 mode too: the fused stem computes in bf16x3,
+                                                                                                   # finer than asked; the library path costs 2.5x its time)
 
 
 def stem_conv_bn_relu_maxpool(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d) -> torch.Tensor:

@@ -77,8 +77,8 @@ def test_each_of_the_five_losses_descends_along_its_own_gradient(device):
 @pytest.mark.timeout(900)
 def test_thirty_optimizer_steps_on_a_fixed_scene_lower_the_loss(device):
     """Thirty steps of the reference's optimizer set-up (config:167-173: AdamW 2e-4, backbone x0.1, clip 35) on one scene, every step with
-    its own ray draw and sampling noise; read on a fixed probe before and after.  The total and the three losses that move by tens of
-    per cent in 30 steps must fall.  (Adam's sign-like first steps make the trajectory chaotic under the float atomics' run-to-run noise:
+    its own ray draw and sampling noise; read on a fixed probe before and after.  The three losses that move by tens of per cent in 30 steps,
+    and the sum of everything but the classification term, must fall.  (Adam's sign-like first steps make the trajectory chaotic under the float atomics' run-to-run noise:
     the classification loss alone ended between 0.24 and 1.35 from 1.11 in repeated runs, the depth loss within +-1 % of its start -- the
     per-loss statement is the first-order test above.)"""
     from test_ddp import _build
@@ -104,9 +104,13 @@ def test_thirty_optimizer_steps_on_a_fixed_scene_lower_the_loss(device):
     assert all(np.isfinite(h["loss"]) for h in hist)
     last = probe()
     print("fixed scene, probe before -> after 30 steps:", {k: (round(first[k], 4), round(last[k], 4)) for k in first})
-    for k in ("loss", "loss_centerness", "loss_bbox", "loss_nvs"):
-        assert last[k] < first[k], f"{k} did not fall: {first[k]:.4f} -> {last[k]:.4f}"
-    assert last["loss_depth"] < 1.03 * first["loss_depth"]
+    # measured over 16 fresh processes (gpurun_out of round 3): centerness 0.749 -> 0.50 - 0.55, bbox 0.804 -> 0.58 - 0.67, nvs 0.115 -> 0.090 - 0.095 every
+    # time; classification 1.11 -> 0.57 - 1.80 and with it the total (3 of 16 runs above its start), depth 1.063 -> 0.97 - 1.12: chaotic, not asserted
+    for k in ("loss_centerness", "loss_bbox", "loss_nvs"):
+        assert last[k] < 0.92 * first[k], f"{k} did not fall: {first[k]:.4f} -> {last[k]:.4f}"
+    rest = lambda d: d["loss"] - d["loss_cls"]
+    assert rest(last) < rest(first), f"the losses other than the classification term did not fall: {rest(first):.4f} -> {rest(last):.4f}"
+    assert last["loss_depth"] < 1.15 * first["loss_depth"] and last["loss_cls"] < 3.0 * first["loss_cls"]
 
 
 @pytest.mark.timeout(900)
