@@ -249,7 +249,8 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
         tile = 128256                                        # the persistent form takes plain convolutions with Cout % 16 == 0
     # unified tiles that write final values: the epilogue straight from the MFMA's C layout (no LDS staging, no barriers)
     base = {100064: 64, 100128: 128, 112864: 12864}.get(tile, tile)
-    direct_ok = (splits == 1 and not transposed and not residual_up2 and pk["cout"] % 32 == 0 and (m + 128) * pk["cout"] * 4 < (1 << 32))
+    direct_ok = (splits == 1 and not transposed and pk["cout"] % 32 == 0 and (m + 128) * pk["cout"] * 4 < (1 << 32)
+                 and (not residual_up2 or _lib.load().ndet_version() >= 105))     # (the upsampled residual in the direct epilogue: ABI 105)
     tile = {64: 100064, 128: 100128, 12864: 112864}[base] if (base in (64, 128, 12864) and direct_ok and DIRECT_EPILOGUE) else base
     ws = torch.empty((m * pk["cout"] * splits * 4,), dtype=torch.uint8, device=x.device) if splits > 1 else None
     i3 = lambda v: (ctypes.c_int * 3)(*v)

@@ -1,6 +1,7 @@
 // Shared by the two implicit-GEMM convolution kernels (conv3d_kernels.hip: exact fp32 MFMA; conv_split_kernels.hip:
 // fp32 operands split into three bf16 terms on the bf16 matrix cores).
 #pragma once
+#include <type_traits>
 #include "ndet_common.hpp"
 
 #define CBK 32          // K step (input channels per step)
@@ -31,6 +32,8 @@ struct Conv3dParams {
     int order = 0;        // bf16x3 grid kernels: which workgroups meet in one XCD's L2 (workgroup b is dispatched to XCD b % 8).  0: grid order (row tiles
                           // fastest).  1: the row tiles of one (column tile, K split) weight slice run on one XCD -- layers whose weights outweigh their
                           // activations (the 20x20x8 / 10x10x4 neck levels: 42 - 170 MB of weight planes, re-streamed from HBM by every XCD in grid order)
+                          // 2: the column tiles of one row tile run on one XCD, side by side in time -- layers whose activations outweigh their weights
+                          // and that have several column tiles (1x1 layers into 256 - 1024 channels: grid order re-reads the rows once per XCD they land on)
     // fp16-pair arithmetic (max_order == 1; conv_split_kernels.hip, SCH 1): both operands are pre-scaled by a power of two so that their largest
     // magnitude sits in [2^14, 2^15) -- the weights once, when their planes are built (`winv` = 1 / that scale), the activations while
     // they are split, by the scale the kernel derives from `amax_in`; the epilogue multiplies the accumulators by the inverse of both.
@@ -108,6 +111,12 @@ __device__ __forceinline__ ConvBlock conv_block(const Conv3dParams& p) {
         const int s = gy * gz, l = b.x + gx * (b.y + gy * b.z);
         const int slice = l % s;
         b.x = l / s; b.y = slice % gy; b.z = slice / gy;
+    } else if (p.order == 2) {
+        // groups of 8 row tiles x gy column tiles: workgroup 8 j + k of a group is (row tile k, column tile j) -- dispatched to XCD k with its
+        // gy - 1 siblings 8 workgroups apart, so the activation rows come from HBM once; the gx % 8 last row tiles keep grid order
+        const int l = b.x + gx * b.y, full = gx & ~7;
+        if (l < full * gy) { const int w = l % (8 * gy); b.x = (l / (8 * gy)) * 8 + (w & 7); b.y = w >> 3; }
+        else { const int r = l - full * gy, rem = gx - full; b.x = full + r % rem; b.y = r / rem; }
     }
     return b;
 }
@@ -142,7 +151,18 @@ __device__ __forceinline__ void conv_store_rows_mapped(const Conv3dParams& p, co
     };
     if ((p.Cout & 3) == 0) {
         constexpr int V = BN / 4;
-        for (int idx = tid; idx < rows * V; idx += NTHR) {
+        // Upsampled residual over consecutive GEMM rows: (ow, oh, od) of the thread's row is divided out once and stepped from then on (a thread's
+        // rows are NTHR / V apart) -- three integer divisions per float4 cost the FPN lateral 0 100 us of its 260 (tools/diag/lat0_probe.py).
+        constexpr bool kWalk = std::is_same<RowMap, ConvLinearRows>::value && NTHR % V == 0;
+        const bool walk = kWalk && !raw && p.res && p.res_up2;
+        int uw = 0, uh = 0, ud = 0;
+        if (walk) { const int m = m_of(tid / V); uw = m % p.OW; uh = (m / p.OW) % p.OH; ud = m / (p.OW * p.OH); }
+        auto step = [&]() {
+            if (!walk) return;
+            uw += NTHR / V;
+            while (uw >= p.OW) { uw -= p.OW; if (++uh == p.OH) { uh = 0; ++ud; } }
+        };
+        for (int idx = tid; idx < rows * V; idx += NTHR, step()) {
             const int row = idx / V, c4 = idx % V;
             const int m = m_of(row), co = n0 + c4 * 4;   // m < 0: the tile row has no output voxel
             if (m < 0 || m >= p.M || co >= p.Cout) continue;
@@ -156,7 +176,8 @@ __device__ __forceinline__ void conv_store_rows_mapped(const Conv3dParams& p, co
                 }
                 if (p.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (p.res) {
-                    const float4 rr = *reinterpret_cast<const float4*>(p.res + res_row(m, orow) * p.Cout + co);
+                    const int64_t rrow = walk ? ((int64_t)ud * p.RH + (uh >> 1)) * p.RW + (uw >> 1) : res_row(m, orow);
+                    const float4 rr = *reinterpret_cast<const float4*>(p.res + rrow * p.Cout + co);
                     v.x = v.x + rr.x; v.y = v.y + rr.y; v.z = v.z + rr.z; v.w = v.w + rr.w;
                 }
                 if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }

@@ -317,8 +317,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
         // ---- direct epilogue: a register of a 32 x 32 tile is 32 consecutive channels of one row = one 128-byte line; residual reads and
         // stores are buffer operations (lane part of the address in one VGPR, the register's row in the scalar offset, rows past M outside the
         // descriptor).  No LDS staging, no barrier: the workgroup's waves drain independently while the CU's other workgroups multiply ----
+        // Upsampled residual (FPN lateral: the coarser map read at (h >> 1, w >> 1)): the rows of a register set are not evenly spaced in the
+        // residual, so (w, h, n) of the lane's first row is divided out once per 32 x 32 tile and stepped along the registers' rows (+1 +1 +1 +5).
         const unsigned obytes = (unsigned)((int64_t)p.M * p.Cout * 4);
-        const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.out), 0, obytes, 0x00020000);
+        const unsigned rbytes = p.res_up2 ? (unsigned)((int64_t)p.OD * p.RH * p.RW * p.Cout * 4) : obytes;
+        const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.out), 0, p.res ? rbytes : obytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, obytes, 0x00020000);
 #pragma unroll
         for (int tb = 0; tb < NT; ++tb) {
@@ -330,10 +333,25 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dPa
                 const int mrow = m0 + wm * WM + ta * 32 + 4 * (lane >> 5);
                 const unsigned vo = (unsigned)(((int64_t)mrow * p.Cout + co) * 4);
                 float rr[16];
+                if (p.res && p.res_up2) {
+                    int uw = mrow % p.OW, uh = (mrow / p.OW) % p.OH, ud = mrow / (p.OW * p.OH);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(((r & 3) + 8 * (r >> 2)) * p.Cout * 4));
-                    rr[r] = p.res ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rres, vo, so, 0)) : 0.0f;
+                    for (int r = 0; r < 16; ++r) {
+                        if (r) {
+                            uw += (r & 3) ? 1 : 5;
+                            if (p.OW >= 5) { if (uw >= p.OW) { uw -= p.OW; if (++uh == p.OH) { uh = 0; ++ud; } } }     // one wrap at most
+                            else while (uw >= p.OW) { uw -= p.OW; if (++uh == p.OH) { uh = 0; ++ud; } }
+                        }
+                        const unsigned ro = ((((unsigned)ud * p.RH + (uh >> 1)) * p.RW + (uw >> 1)) * p.Cout + co) * 4u;   // < 4 GB (launcher)
+                        // rows past M: an offset outside the descriptor (the load returns 0, the store below is dropped the same way)
+                        rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rres, (mrow + (r & 3) + 8 * (r >> 2) < p.M) ? ro : 0xfffffff0u, 0, 0));
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(((r & 3) + 8 * (r >> 2)) * p.Cout * 4));
+                        rr[r] = p.res ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rres, vo, so, 0)) : 0.0f;
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1777,8 +1795,8 @@ int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn)
     p.nt = (p.splits <= 1 || p.transposed) && (int64_t)p.M * p.Cout * 4 * (p.transposed ? 8 : 1) >= conv_nt_bytes() ? 1 : 0;
     if (tile >= 100000 && (tile - 100000 == 64 || tile - 100000 == 128 || tile - 100000 == 12864)) {   // 100064 / 100128 / 112864: direct epilogue
         tile -= 100000;
-        NDET_REQUIRE(!p.transposed && p.splits == 1 && !p.res_up2 && p.Cout % 32 == 0 && ((int64_t)p.M + 128) * p.Cout * 4 < ((int64_t)1 << 32),
-                     NDET_E_UNSUPPORTED, "%s: the direct epilogue needs splits == 1, a plain residual, Cout %% 32 == 0 and an output below 4 GB", fn);
+        NDET_REQUIRE(!p.transposed && p.splits == 1 && p.Cout % 32 == 0 && ((int64_t)p.M + 128) * p.Cout * 4 < ((int64_t)1 << 32),
+                     NDET_E_UNSUPPORTED, "%s: the direct epilogue needs splits == 1, no transposition, Cout %% 32 == 0 and an output below 4 GB", fn);
         p.direct = 1;
     }
     const int64_t big_tiles = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
@@ -1793,7 +1811,10 @@ int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn)
         if (NDET_ORDER_DEFAULT < 0) {
             p.order = 0;
             if (!p.transposed && mt > 1 && nt * p.splits > 1 && save_w > save_a && w_bytes > (8 << 20)) p.order = 1;
-            // (the mirror case -- the column tiles of one row tile on one XCD -- would need (nt - 1) tm 4 > 6 Cout taps: no tile of this family)
+            // the mirror case: weights small enough to sit in every L2 (1x1 layers), several column tiles, the rows re-read once per XCD otherwise
+            static const bool order2 = !getenv("NDET_NO_ORDER2");
+            if (order2 && p.order == 0 && !p.transposed && nt > 1 && mt >= 16 && w_bytes <= (2 << 20) && save_a >= (8 << 20) &&
+                (tile == 64 || tile == 128 || tile == 12864 || tile == 128256)) p.order = 2;
         }
     }
     int rc;

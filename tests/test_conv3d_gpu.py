@@ -192,6 +192,7 @@ def test_split_conv_is_fp32_accurate_against_fp64(device, tile):
             got_split = conv3d.conv3d_ndhwc(x.to(device), pk, tile=tile, splits=1).cpu()
         finally:
             conv3d.set_arithmetic(prev)
+            conv3d.DIRECT_EPILOGUE = True
         got_f32 = conv3d.conv3d_ndhwc(x.to(device), pk, splits=1).cpu()
     scale = float(ref64.abs().mean())
     e_split = float((got_split.double() - ref64).abs().max()) / scale
@@ -230,6 +231,7 @@ def test_split_conv_wave_specialised_tile(device, cin, cout, grid, k, stride, tr
             got = conv3d.conv3d_ndhwc(x.to(device), pk, residual=None if res is None else res.to(device), relu=relu, splits=splits, tile=128256)
         finally:
             conv3d.set_arithmetic(prev)
+            conv3d.DIRECT_EPILOGUE = True
     assert got.shape == ref.shape
     scale = max(1.0, float(ref.abs().max()))
     assert float((got.cpu() - ref).abs().max()) <= 2e-5 * scale
@@ -298,6 +300,7 @@ def test_split_conv_persistent_wave_specialised_tile(device, cin, cout, grid, k,
                 one_shot = conv3d.conv3d_ndhwc(x.to(device), pk, tile=128256, **kw)
         finally:
             conv3d.set_arithmetic(prev)
+            conv3d.DIRECT_EPILOGUE = True
     assert got.shape == ref.shape
     scale = max(1.0, float(ref.abs().max()))
     assert float((got.cpu() - ref).abs().max()) <= 2e-5 * scale
@@ -455,6 +458,7 @@ def test_conv_chain_matches_torch_fp32_and_the_two_launches(device, cin, mid, co
             two16 = conv2d_nhwc(conv2d_nhwc(x.to(device), pk2, relu=1), pk3, residual=rd, relu=relu3)
         finally:
             conv3d.set_arithmetic(prev)
+            conv3d.DIRECT_EPILOGUE = True
     scale = max(1.0, float(ref.abs().max()))
     assert got.shape == ref.shape
     assert float((got.cpu() - ref).abs().max()) <= 2e-5 * scale
@@ -498,6 +502,7 @@ def test_fused_stem_matches_torch_fp32(device, nhw, layout):
 def test_direct_epilogue_equals_the_staged_epilogue(device, cin, cout, nhw, k, stride, relu, use_res, tile):
     """The unified tiles' direct epilogue (stores from the MFMA's C layout through buffer operations, tile codes 100064 / 100128 / 112864)
     against the LDS-staged one: the same values, bit for bit (ragged last tile, residual, both ReLU positions, stride 2)."""
+    from nerfdet_amd import conv3d
     from nerfdet_amd.conv3d import conv2d_nhwc, packed
     torch.manual_seed(cin + cout + k)
     conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=False).to(device)
@@ -508,6 +513,41 @@ def test_direct_epilogue_equals_the_staged_epilogue(device, cin, cout, nhw, k, s
         pk = packed([conv], bn)
         oh, ow = (nhw[1] + 2 * (k // 2) - k) // stride + 1, (nhw[2] + 2 * (k // 2) - k) // stride + 1
         res = torch.randn(nhw[0], oh, ow, cout, device=device) if use_res else None
-        staged = conv2d_nhwc(x, pk, residual=res, relu=relu, tile=tile - 100000, splits=1)
+        conv3d.DIRECT_EPILOGUE = False           # (otherwise the plain tile codes are promoted to the direct form as well)
+        try:
+            staged = conv2d_nhwc(x, pk, residual=res, relu=relu, tile=tile - 100000, splits=1)
+        finally:
+            conv3d.DIRECT_EPILOGUE = True
         direct = conv2d_nhwc(x, pk, residual=res, relu=relu, tile=tile)
     assert torch.equal(direct, staged)
+
+
+@pytest.mark.parametrize("arith", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("grid", [(5, 9, 7), (3, 21, 30), (2, 8, 3)])
+def test_upsampled_residual_rows_on_every_tile(device, arith, grid):
+    """FPN lateral (1x1 conv + bias + the coarser lateral read nearest-x2-upsampled, neck fpn.py behind nerfdet.py:140): the staged epilogue
+    steps the residual's (w, h, n) along a thread's rows instead of dividing per element -- maps narrower than the step (OW = 7, 3), several
+    maps per tile and tiles that end mid-row, on every tile family (staged and direct epilogues), against fp64."""
+    from nerfdet_amd import conv3d
+    torch.manual_seed(sum(grid))
+    n, h, w = grid
+    conv = nn.Conv2d(64, 256, 1)
+    x = torch.randn(n, h, w, 64)
+    up = torch.randn(n, (h + 1) // 2, (w + 1) // 2, 256)
+    with torch.no_grad():
+        ref = conv.double()(x.permute(0, 3, 1, 2).double()).permute(0, 2, 3, 1) + up.double()[:, torch.arange(h) // 2][:, :, torch.arange(w) // 2]
+        conv.float()
+        pk = conv3d.packed([conv.to(device)])
+        prev = conv3d.set_arithmetic(arith)
+        try:
+            for tile in (0, 64, 128, 12864, 128256, 129256, 129064, 100064, 100128, 112864):
+                conv3d.DIRECT_EPILOGUE = tile in (100064, 100128, 112864)      # the plain codes of the unified tiles: the staged epilogue
+                got = conv3d.conv2d_nhwc(x.to(device), pk, residual=up.to(device), residual_up2=True, tile=tile, splits=1 if tile else 0)
+                assert float((got.cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), tile
+                if tile in (100064, 100128, 112864):
+                    conv3d.DIRECT_EPILOGUE = False
+                    staged = conv3d.conv2d_nhwc(x.to(device), pk, residual=up.to(device), residual_up2=True, tile={100064: 64, 100128: 128, 112864: 12864}[tile], splits=1)
+                    assert torch.equal(got, staged), tile
+        finally:
+            conv3d.set_arithmetic(prev)
+            conv3d.DIRECT_EPILOGUE = True
