@@ -296,8 +296,13 @@ __device__ __forceinline__ void conv_split_mainloop(const Conv3dParams& p, const
     }
 }
 
+#ifndef UNI128_F16_WGS
+#define UNI128_F16_WGS 3     // fp16 pair, 128 x 128: 40 KB of LDS per workgroup would admit four per CU (1 024 slots for the 944 tiles of the stage-3
+                             // conv3 layers, which now take two rounds), but at 128 registers the kernel spills 316 bytes per lane (162 needed): three
+#endif
+template <int BM, int BN, int SCH> constexpr int uni_min_wgs() { return (SCH == 1 && BM == 128 && BN == 128) ? UNI128_F16_WGS : 2; }
 template <int BM, int BN, int WGM, int WGN, int SCH = 0>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void k_conv_split(const Conv3dParams p, const uint16_t* __restrict__ wsplit) {
+__global__ __launch_bounds__(64 * WGM * WGN, (uni_min_wgs<BM, BN, SCH>())) void k_conv_split(const Conv3dParams p, const uint16_t* __restrict__ wsplit) {
     constexpr int NTHR = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
