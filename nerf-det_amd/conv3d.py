@@ -52,7 +52,7 @@ class _AmaxSlots:
     has to be zero before the producing launch, and the zeros come from one fill per 4096 slots, stream-ordered before every launch that follows
     on that stream."""
 
-    WIDTH = 256     # floats per slot: 8 sub-slots (one per XCD) 128 bytes apart (csrc/conv_common.hpp::conv_amax_commit / conv_amax_read)
+    WIDTH = int(__import__("os").environ.get("NDET_AMAX_WIDTH", 256))     # floats per slot (the environment variable: measurement builds with another layout): 8 sub-slots (one per XCD) 128 bytes apart (csrc/conv_common.hpp::conv_amax_commit / conv_amax_read)
 
     def __init__(self):
         self.pools = {}

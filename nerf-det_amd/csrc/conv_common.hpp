@@ -79,9 +79,10 @@ __device__ __forceinline__ float conv_xscale(const float* amax) { return conv_xs
 // Every lane of the calling wave must be active (conv_amax_read shuffles).
 __device__ __forceinline__ float conv_oscale(const Conv3dParams& p) { return p.amax_in ? conv_xinv_of(conv_amax_read(p.amax_in)) * p.winv : 1.0f; }
 
-// max |v| of a WORKGROUP -> one L2-local atomic on this XCD's sub-slot, skipped when the sub-slot already holds as much (non-negative floats
-// order like their bit patterns; the sub-slot only grows, so a stale read costs a needless atomic, never a missed one).  Every thread of the
-// workgroup must arrive (there is a barrier inside).
+// max |v| of a WORKGROUP -> one L2-local atomic on this XCD's sub-slot (non-negative floats order like their bit patterns).  Sent without
+// looking at the sub-slot first: a read in front of it (to skip the atomic when the sub-slot already holds as much) made every workgroup wait
+// for a load behind its own stores -- 0.11 ms of a cfg2 step (tools/diag/ab_variants.sh, tools/diag/amax_commit_variants.patch).  Every
+// thread of the workgroup must arrive (there is a barrier inside).
 __device__ __forceinline__ void conv_amax_commit(float* slot, float mx) {
     __shared__ float wg_amax[16];
 #pragma unroll
@@ -93,7 +94,7 @@ __device__ __forceinline__ void conv_amax_commit(float* slot, float mx) {
         for (int i = 1; i < nw; ++i) mx = fmaxf(mx, wg_amax[i]);
         const unsigned bits = __float_as_uint(mx);
         unsigned* sub = reinterpret_cast<unsigned*>(slot) + conv_xcc_id() * NDET_AMAX_STRIDE;
-        if (bits > __builtin_nontemporal_load(sub)) atomicMax(sub, bits);
+        if (bits) atomicMax(sub, bits);
     }
 }
 
