@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void k_co
     __syncthreads();
 
     float mx = 0.0f;
-    conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0, BM, n0, tid, ztap, blockIdx.z, mx);
+    conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0, BM, n0, tid, ztap, blockIdx.z, mx, 1.0f);
     if (p.amax_out && conv_writes_final(p)) conv_amax_commit(p.amax_out, mx);
 }
 

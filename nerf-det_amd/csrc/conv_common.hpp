@@ -78,6 +78,8 @@ __device__ __forceinline__ float conv_xscale(const float* amax) { return conv_xs
 // what the accumulators are multiplied by before the epilogue's affine: 1 except in the fp16-pair arithmetic (exact: a power of two).
 // Every lane of the calling wave must be active (conv_amax_read shuffles).
 __device__ __forceinline__ float conv_oscale(const Conv3dParams& p) { return p.amax_in ? conv_xinv_of(conv_amax_read(p.amax_in)) * p.winv : 1.0f; }
+__device__ __forceinline__ float conv_amax_in(const Conv3dParams& p) { return p.amax_in ? conv_amax_read(p.amax_in) : 0.0f; }
+__device__ __forceinline__ float conv_oscale_of(const Conv3dParams& p, float amax_in) { return p.amax_in ? conv_xinv_of(amax_in) * p.winv : 1.0f; }
 
 // max |v| of a WORKGROUP -> one L2-local atomic on this XCD's sub-slot (non-negative floats order like their bit patterns).  Sent without
 // looking at the sub-slot first: a read in front of it (to skip the atomic when the sub-slot already holds as much) made every workgroup wait
@@ -138,13 +140,13 @@ struct ConvLinearRows {
     __device__ __forceinline__ int operator()(int row) const { return first + row; }
 };
 
-// `mx`: running max |v| of the final values this thread stored (the caller commits it once, conv_amax_commit).
+// `mx`: running max |v| of the final values this thread stored (the caller commits it once, conv_amax_commit).  `osc`: conv_oscale_of(p, amax)
+// with the slot read at KERNEL ENTRY (conv_amax_in: a scalar register over the K walk instead of a global load in front of the stores).
 template <int BN, int NTHR, typename RowMap>
 __device__ __forceinline__ void conv_store_rows_mapped(const Conv3dParams& p, const float* Cs, int cld, int rows, int n0, int tid, int ztap,
-                                                       int zsplit, RowMap m_of, float& mx) {
+                                                       int zsplit, RowMap m_of, float& mx, float osc) {
     const bool raw = (!p.transposed && p.splits > 1);
     float* dst = raw ? p.partial + (int64_t)zsplit * p.M * p.Cout : p.out;
-    const float osc = conv_oscale(p);
     auto res_row = [&](int m, int64_t orow) -> int64_t {
         if (!p.res_up2) return orow;
         const int ow = m % p.OW, oh = (m / p.OW) % p.OH, od = m / (p.OW * p.OH);
@@ -212,8 +214,8 @@ __device__ __forceinline__ void conv_store_rows_mapped(const Conv3dParams& p, co
 // tile rows are consecutive GEMM rows starting at m_first
 template <int BN, int NTHR>
 __device__ __forceinline__ void conv_store_rows(const Conv3dParams& p, const float* Cs, int cld, int m_first, int rows, int n0, int tid,
-                                                int ztap, int zsplit, float& mx) {
-    conv_store_rows_mapped<BN, NTHR>(p, Cs, cld, rows, n0, tid, ztap, zsplit, ConvLinearRows{m_first}, mx);
+                                                int ztap, int zsplit, float& mx, float osc) {
+    conv_store_rows_mapped<BN, NTHR>(p, Cs, cld, rows, n0, tid, ztap, zsplit, ConvLinearRows{m_first}, mx, osc);
 }
 // does this launch's epilogue write the layer's final values (split-K launches write partials: their reduce pass commits the maximum)
 __device__ __forceinline__ bool conv_writes_final(const Conv3dParams& p) { return p.transposed || p.splits <= 1; }

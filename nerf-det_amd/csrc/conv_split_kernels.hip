@@ -313,11 +313,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (uni_min_wgs<BM, BN, SCH>())) void 
     const int m0 = blk.x * BM, n0 = blk.y * BN;
     f32x16 acc[MT][NT];
     int ztap;
+    const float amax_in = conv_amax_in(p);
     conv_split_mainloop<BM, BN, WGM, WGN, SCH>(p, wsplit, lds16, acc, ztap);
+    const float osc = conv_oscale_of(p, amax_in);
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     if (p.direct) {
-        const float osc = conv_oscale(p);
         float mx = 0.0f;
         // ---- direct epilogue: a register of a 32 x 32 tile is 32 consecutive channels of one row = one 128-byte line; residual reads and
         // stores are buffer operations (lane part of the address in one VGPR, the register's row in the scalar offset, rows past M outside the
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (uni_min_wgs<BM, BN, SCH>())) void 
                         Cs[(ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CLDC + wn * WN + tb * 32 + (lane & 31)] = acc[ta][tb][r];
         }
         __syncthreads();
-        conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, ztap, blk.z, mx);
+        conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, ztap, blk.z, mx, osc);
         __syncthreads();
     }
     if (p.amax_out && conv_writes_final(p)) conv_amax_commit(p.amax_out, mx);
@@ -440,7 +441,9 @@ __global__ __launch_bounds__(256, MID == 64 ? (SCH == 1 ? CHAIN64_F16_WGS : 3) :
     const int m0 = blockIdx.x * BM;
     f32x16 acc[MT][NT];
     int ztap;
+    const float amax_in = conv_amax_in(p);
     conv_split_mainloop<BM, BN, WGM, WGN, SCH>(p, wsplit, lds16, acc, ztap);
+    const float osc = conv_oscale_of(p, amax_in);
 
     // ---- intermediate: BN + ReLU in place.  fp16 pair: its scale comes from the workgroup's own maximum (the tile is multiplied by W3 here and
     // nowhere else, so the scale only has to be the same for the rows and K slices of this workgroup's chained GEMM) ----
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(const WgradParams g, con
         }
         __syncthreads();
         float mx_unused = 0.0f;
-        conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, 0, blockIdx.z, mx_unused);
+        conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, 0, blockIdx.z, mx_unused, 1.0f);
         __syncthreads();
     }
 }
@@ -844,6 +847,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
     const int wm = (wave & 3) >> 1, wn = wave & 1;
     const ConvBlock blk = conv_block(p);
     const int m0 = blk.x * WS_BM, n0 = blk.y * WS_BN;
+    const float amax_in = conv_amax_in(p);
     const int stid = tid & 255;
     const int akq = stid & 7, arow_ = stid >> 3;
     const int bkg = stid & 3, brow_ = stid >> 2;
@@ -1059,7 +1063,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
                         Cs[(ta * 16 + (lane >> 4) * 4 + r) * CLDC + wn * 128 + tb * 16 + (lane & 15)] = acc[ta][tb][r];
         }
         __syncthreads();
-        conv_store_rows<WS_BN, 512>(p, Cs, CLDC, m0 + h * 64, 64, n0, tid, ztap, blk.z, mx);
+        conv_store_rows<WS_BN, 512>(p, Cs, CLDC, m0 + h * 64, 64, n0, tid, ztap, blk.z, mx, conv_oscale_of(p, amax_in));
         __syncthreads();
     }
     if (p.amax_out && conv_writes_final(p)) conv_amax_commit(p.amax_out, mx);
@@ -1489,6 +1493,7 @@ __global__ __launch_bounds__(64 * (2 * WGN + NPROD), 1) void k_conv_split_halo(c
     const int phi = pb % g.nph;
     const int pdi = pb / g.nph;
     const int d0 = pdi << g.ltd, h0 = phi << g.lth, w0 = pwi << g.ltw;
+    const float amax_in = conv_amax_in(p);
 
     const int nch_all = p.Cin / CBK;
     int cb = 0, ce = nch_all;
@@ -1690,7 +1695,7 @@ __global__ __launch_bounds__(64 * (2 * WGN + NPROD), 1) void k_conv_split_halo(c
                         Cs[(ta * 16 + (lane >> 4) * 4 + r) * CLDC + wn * (16 * NT16) + tb * 16 + (lane & 15)] = acc[ta][tb][r];
         }
         __syncthreads();
-        conv_store_rows_mapped<BN, NTHR>(p, Cs, CLDC, 64, n0, tid, 0, blk.z, HaloRowMap{h * 64, g.ltw, g.lth, d0, h0, w0, p.OD, p.OH, p.OW}, mx);
+        conv_store_rows_mapped<BN, NTHR>(p, Cs, CLDC, 64, n0, tid, 0, blk.z, HaloRowMap{h * 64, g.ltw, g.lth, d0, h0, w0, p.OD, p.OH, p.OW}, mx, conv_oscale_of(p, amax_in));
         __syncthreads();
     }
     if (p.amax_out && conv_writes_final(p)) conv_amax_commit(p.amax_out, mx);
