@@ -72,6 +72,9 @@ class _AmaxSlots:
 
 
 AMAX = _AmaxSlots()
+# measurement only: no epilogue commits a maximum, every fp16-pair launch takes a separate ndet_amax_f32 pass over its input instead --
+# the convolution kernels then run on the same operands as in production, without their commit
+NO_AMAX_COMMIT = bool(__import__("os").environ.get("NDET_NO_AMAX_COMMIT"))
 amax_fallbacks = 0      # how many inputs needed their own ndet_amax_f32 pass (diagnostic: the hot path should carry the attribute)
 
 
@@ -262,6 +265,8 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
     if ARITHMETIC == "f16x2" and pk.get("arith"):
         arith = pk["arith"]            # pinned packs: training (conv_train.py: the weights change every step) and the point MLPs (packed_linear)
         want_amax = False              # (a reader in the fp16-pair arithmetic takes its own pass, amax_of)
+    if NO_AMAX_COMMIT:
+        want_amax = False
     if ARITHMETIC != "f16x2":
         planes = split_planes(pk)
         fn = lib.ndet_conv_ndhwc_bf16 if arith == "bf16" else lib.ndet_conv_ndhwc_split
@@ -491,12 +496,13 @@ def conv2d_chain_nhwc(x: torch.Tensor, pk: dict, pk3: dict, residual: Optional[t
     name = f"k_conv_split_chain<{mid}>"
     if ARITHMETIC == "f16x2":
         (p1, w1inv), (p3, w3inv) = split_planes_f16(pk), split_planes_f16(pk3)
-        in_amax, out_amax = amax_of(x), AMAX.take(x.device)
+        in_amax, out_amax = amax_of(x), (None if NO_AMAX_COMMIT else AMAX.take(x.device))
         name += "/f16x2"
         thunk = lambda: check(lib.ndet_conv_chain_arith(_ptr(x), _ptr(p1), n, h, w, cin, mid, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw), _ptr(pk["scale"]),
                                                         _ptr(pk["shift"]), _ptr(p3), cout, _ptr(pk3["scale"]), _ptr(pk3["shift"]), _ptr(residual), relu,
                                                         _ptr(out), 1, _ptr(in_amax), w1inv, w3inv, _ptr(out_amax), st), "conv_chain_arith")
-        _tag_amax(out, out_amax)
+        if out_amax is not None:
+            _tag_amax(out, out_amax)
     else:
         p1, p3 = split_planes(pk), split_planes(pk3)
         thunk = lambda: check(lib.ndet_conv_chain_split(_ptr(x), _ptr(p1), n, h, w, cin, mid, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw), _ptr(pk["scale"]),
