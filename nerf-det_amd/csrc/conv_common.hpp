@@ -28,7 +28,7 @@ struct Conv3dParams {
     int max_order;        // bf16x3 kernels: products (pa, pb) with pa + pb <= max_order are issued -- 2: all six (fp32-class result),
                           // 0: a0*b0 only = both operands rounded to bf16, fp32 accumulate (the "bf16" arithmetic of BASELINE configs 3/5)
     int direct = 0;       // unified bf16x3 tiles: 1 = the epilogue stores straight from the MFMA's C layout with buffer operations (no LDS staging,
-                          // no barriers; needs splits == 1, no transposed / upsampled-residual mode, Cout % 32 == 0, output < 4 GB)
+                          // no barriers; needs splits == 1, no transposed mode, Cout % 32 == 0, output < 4 GB)
     int order = 0;        // bf16x3 grid kernels: which workgroups meet in one XCD's L2 (workgroup b is dispatched to XCD b % 8).  0: grid order (row tiles
                           // fastest).  1: the row tiles of one (column tile, K split) weight slice run on one XCD -- layers whose weights outweigh their
                           // activations (the 20x20x8 / 10x10x4 neck levels: 42 - 170 MB of weight planes, re-streamed from HBM by every XCD in grid order)
