@@ -259,7 +259,12 @@ int ndet_split_weights_bf16x3_torch(const float* w_torch, int taps, int Cout, in
 /* Same contract as ndet_conv_ndhwc / the transposed form of ndet_conv3d_ndhwc, computed on the bf16 matrix cores:
  * weights as tiled bf16 planes (taps, Cin/32, 3, Cout, 32) from ndet_split_weights_bf16x3, activations split on the fly; the six
  * products of order <= 2 are accumulated in fp32 (error at the level of an fp32 FMA chain).  transposed = 1: k2 s2
- * ConvTranspose3d (kernel/stride must be 2, pad 0; 8 taps).  tile: 0 auto, 64, 128, 12864 (128 x 64).
+ * ConvTranspose3d (kernel/stride must be 2, pad 0; 8 taps).  tile (rows x output channels of a workgroup's tile): 0 auto; 64 (64 x 64), 128
+ * (128 x 128), 12864 (128 x 64): the unified tiles, LDS-staged epilogue; 100064 / 100128 / 112864: the same tiles storing straight from the
+ * accumulators (splits == 1, not transposed, Cout % 32 == 0, output < 4 GB; plain and nearest-x2 residual); 128256: wave-specialised 128 x 256;
+ * 129256 / 129257 (eight consumer waves) / 129064 (64-row tiles): its persistent form (plain convolutions, Cout % 16 == 0, <= 32 taps);
+ * 3128 / 3256 / 3257 / 3258: halo-stationary 128-voxel patch x 128 / 256 channels (stride 1, odd kernel, same padding, more than one tap;
+ * 3257: two consumer waves per SIMD, 3258: eight producer waves).  Results are bit-identical across tiles of one family for a given K split.
  * Replaces the same reference modules as ndet_conv3d_ndhwc (necks/imvoxelnet.py:36-67,233-260,
  * dense_heads/imvoxel_head_v2.py:45-49) and the mmdet ResNet/FPN convolutions behind nerfdet.py:140. */
 int ndet_conv_ndhwc_split(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
