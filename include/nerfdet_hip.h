@@ -264,7 +264,8 @@ int ndet_split_weights_bf16x3_torch(const float* w_torch, int taps, int Cout, in
  * accumulators (splits == 1, not transposed, Cout % 32 == 0, output < 4 GB; plain and nearest-x2 residual); 128256: wave-specialised 128 x 256;
  * 129256 / 129257 (eight consumer waves) / 129064 (64-row tiles): its persistent form (plain convolutions, Cout % 16 == 0, <= 32 taps);
  * 3128 / 3256 / 3257 / 3258: halo-stationary 128-voxel patch x 128 / 256 channels (stride 1, odd kernel, same padding, more than one tap;
- * 3257: two consumer waves per SIMD, 3258: eight producer waves).  Results are bit-identical across tiles of one family for a given K split.
+ * 3257: two consumer waves per SIMD, 3258: eight producer waves).  The staged and direct forms of a unified tile, and the one-shot and persistent
+ * forms of the wave-specialised tile, give bit-identical results (tests/test_conv3d_gpu.py).
  * Replaces the same reference modules as ndet_conv3d_ndhwc (necks/imvoxelnet.py:36-67,233-260,
  * dense_heads/imvoxel_head_v2.py:45-49) and the mmdet ResNet/FPN convolutions behind nerfdet.py:140. */
 int ndet_conv_ndhwc_split(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
