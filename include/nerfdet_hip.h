@@ -296,6 +296,20 @@ int ndet_conv_chain_split(const float* in, const uint16_t* w_planes, int D, int 
                           int Cout, const float* scale3, const float* shift3, const float* residual, int relu3, float* out,
                           int max_order, void* stream);
 
+/* A6 fused: [posenc(points) | global_feat] -> 4 x (Linear 256 + ReLU) -> sigma layer over [h | input] -> alpha = 1 - exp(-relu(sigma)), one launch,
+ * the 256-wide activations never leave the CU.  Replaces VanillaNeRFRadianceField.query_density (mmdet3d/models/model_utils/nerf_mlp.py:224-227;
+ * NerfMLP.query_density :138-144, MLP.forward :80-90 with skip_layer = 3, SinusoidalEncoder.forward :181-197) and the alpha line of
+ * detectors/nerfdet.py:254-257 for the shipped architecture (net_depth 4, net_width 256).  points (3, N); global_feat (N, F) or null with F = 0;
+ * K0 = 63 + F rounded up to a multiple of 32 (<= 256) = the padded input width the first layer's planes were built for.
+ * w_planes_host / w_inv_scale_host / bias_host: HOST arrays of 4 entries -- device pointers to the fp16-pair planes of each hidden layer
+ * (ndet_split_weights_f16x2 of the (1, 256, K) packed weight, K = K0 for layer 0 and 256 after it), 1 / their scales, device pointers to the
+ * biases (256).  w_sigma (256 + 63 + F) over [h | input], b_sigma (1).  Arithmetic: fp16-pair products, fp32 accumulate, the activation scale
+ * taken PER ROW (a row's error is 2^-22 of its own magnitude -- the rows of voxels no view sees hold ~1e9, nerfdet.py:236-243).
+ * Outputs: alpha (N); raw_sigma (N, before the ReLU) and h_out (N, 256, the trunk output) may be null. */
+int ndet_point_mlp_alpha(const float* points, const float* global_feat, int N, int F, int K0, int hidden, const uint16_t* const* w_planes_host,
+                         const float* w_inv_scale_host, const float* const* bias_host, const float* w_sigma, const float* b_sigma,
+                         float* raw_sigma, float* alpha, float* h_out, void* stream);
+
 /* fp16-PAIR arithmetic of the same convolutions (arith = 1 below): every fp32 operand, pre-scaled by a power of two so that the tensor's
  * largest magnitude sits in [2^14, 2^15), is written as hi + lo with hi = fp16(x), lo = fp16(x - hi) (2 x 11 significand bits + sign:
  * |x - hi - lo| <= 2^-23 |x| for every element above ~2^-16 of the tensor's maximum), and a*b is accumulated in fp32 as the THREE products
@@ -311,6 +325,17 @@ int ndet_split_weights_f16x2(const float* w_packed, int taps, int Cout, int Cin,
 /* max |x| over n floats, atomically maxed (as uint bits) into *slot, which the caller zeroed: the `in_amax` of a fp16-pair convolution
  * whose input no convolution kernel wrote (the voxel volume of nerfdet.py:363-420, the MLP inputs of nerf_mlp.py:200-245). */
 int ndet_amax_f32(const float* x, int64_t n, float* slot, void* stream);
+
+/* Floats per amax slot (8 per-XCD sub-slots x 32 floats = 1 KiB): the host allocates slots of exactly this size (nerfdet_amd/conv3d.py asserts it
+ * at load time; a narrower slot would make the kernels' sub-slot atomics run into the neighbouring tensor's slot).  Serves the same convolutions as ndet_amax_f32 (mmdet3d/models/necks/imvoxelnet.py:36-67); the reference
+ * itself has no counterpart. */
+int ndet_amax_slot_floats(void);
+
+/* Measurement knobs of the convolution launchers, set explicitly by profiling scripts (tools/layer_times.py) -- never read from the environment, so
+ * a production process cannot pick them up by accident.  "nt_bytes": outputs of at least this many bytes are written with non-temporal stores
+ * (default 32 MiB); "order2": 1 / 0 = deal the column tiles of a row tile to one XCD or keep grid order.  Neither changes a result bit.
+ * HOST string.  No reference counterpart (the reference's harness, tools/benchmark.py:63-89, times the model only). */
+int ndet_measurement_knob(const char* name_host, int64_t value);
 
 /* ndet_conv_ndhwc_split / ndet_conv_ndhwc_bf16 (necks/imvoxelnet.py:36-67,233-260, imvoxel_head_v2.py:45-49, the backbone behind
  * nerfdet.py:140) with the arithmetic as an argument: arith 0 = bf16x3 (six products), 1 = fp16 pair (three

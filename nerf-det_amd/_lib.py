@@ -56,6 +56,9 @@ SIGNATURES = {
     "ndet_split_weights_f16x2": ([_P, c_int, c_int, c_int, c_float, _P, _P], c_int),
     "ndet_conv_ndhwc_arith": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P, _P], c_int),
     "ndet_amax_f32": ([_P, ctypes.c_int64, _P, _P], c_int),
+    "ndet_amax_slot_floats": ([], c_int),
+    "ndet_point_mlp_alpha": ([_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
+    "ndet_measurement_knob": ([c_char_p, c_int64], c_int),
     "ndet_conv_chain_arith": ([_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_float, c_float, _P, _P], c_int),
     "ndet_split_weights_bf16x3_torch": ([_P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_conv_ndhwc_split": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P], c_int),

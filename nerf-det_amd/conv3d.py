@@ -52,7 +52,8 @@ class _AmaxSlots:
     has to be zero before the producing launch, and the zeros come from one fill per 4096 slots, stream-ordered before every launch that follows
     on that stream."""
 
-    WIDTH = int(__import__("os").environ.get("NDET_AMAX_WIDTH", 256))     # floats per slot (the environment variable: measurement builds with another layout): 8 sub-slots (one per XCD) 128 bytes apart (csrc/conv_common.hpp::conv_amax_commit / conv_amax_read)
+    WIDTH = 256     # floats per slot = NDET_AMAX_SUB x NDET_AMAX_STRIDE of csrc/conv_common.hpp (8 sub-slots, one per XCD, 128 bytes apart); checked
+                    # against the library at load time (_lib.load: ndet_amax_slot_floats)
 
     def __init__(self):
         self.pools = {}
@@ -72,23 +73,65 @@ class _AmaxSlots:
 
 
 AMAX = _AmaxSlots()
-# measurement only: no epilogue commits a maximum, every fp16-pair launch takes a separate ndet_amax_f32 pass over its input instead --
-# the convolution kernels then run on the same operands as in production, without their commit
-NO_AMAX_COMMIT = bool(__import__("os").environ.get("NDET_NO_AMAX_COMMIT"))
+# measurement only (set by tools/diag/amax_cost.sh through conv3d.measurement_mode, never by the environment of a production run): no
+# epilogue commits a maximum, every fp16-pair launch takes a separate ndet_amax_f32 pass over its input instead
+NO_AMAX_COMMIT = False
 amax_fallbacks = 0      # how many inputs needed their own ndet_amax_f32 pass (diagnostic: the hot path should carry the attribute)
 
 
-def _tag_amax(t: torch.Tensor, slot: torch.Tensor) -> None:
-    """Attach the slot together with the tensor's version counter: an in-place write to the tensor (or to a view of it) afterwards makes the
-    slot stale, and a stale maximum could overflow fp16 -- amax_of then takes a fresh pass instead of trusting it."""
+def measurement_mode(no_amax_commit: bool = False) -> None:
+    """Explicit switch for the measurement builds of DESIGN.md 11.2 (was an environment variable: a stray NDET_NO_AMAX_COMMIT in a production shell
+    changed the production path's launches)."""
+    global NO_AMAX_COMMIT
+    NO_AMAX_COMMIT = bool(no_amax_commit)
+
+
+# ---- when is a tensor's slot still the maximum of its contents? ----
+# Two kinds of writes can make it stale: torch's own in-place operations (seen through the tensor's version counter -- which INFERENCE tensors do
+# not have: ``t._version`` raises under torch.inference_mode()) and this library's kernels writing through raw pointers into caller-owned
+# buffers (``out=`` arguments: invisible to torch, counted here per storage).  A stale maximum that is too small overflows fp16 silently, so
+# anything that cannot be proven fresh takes a new ndet_amax_f32 pass instead.
+_RAW_WRITES = {}    # storage address -> library writes through raw pointers into caller-owned tensors
+
+
+def _stamp(t: torch.Tensor):
+    try:
+        v = t._version
+    except RuntimeError:        # inference tensor: no version counter
+        v = None
+    return v, _RAW_WRITES.get(t.untyped_storage().data_ptr(), 0)
+
+
+def note_raw_write(t: torch.Tensor) -> None:
+    """A kernel of this library wrote ``t`` through its raw pointer (an ``out=`` buffer the caller owns): every slot tagged on a tensor over the
+    same storage is stale from here on."""
+    key = t.untyped_storage().data_ptr()
+    _RAW_WRITES[key] = _RAW_WRITES.get(key, 0) + 1
+    t.__dict__.pop("_ndet_amax", None)
+
+
+def _tag_amax(t: torch.Tensor, slot: torch.Tensor, produced: bool = True) -> None:
+    """Attach the slot together with the tensor's write stamp.  ``produced``: the library itself just wrote ``t`` (or ``t`` is a view it made of
+    such a tensor).  An inference tensor that the library did not produce is never tagged: torch could write it in place unseen."""
+    stamp = _stamp(t)
+    if stamp[0] is None and not produced:
+        return
     t._ndet_amax = slot
-    t._ndet_amax_version = t._version
+    t._ndet_amax_stamp = stamp
+
+
+def _amax_tag(t: torch.Tensor):
+    """The tensor's slot if it is provably fresh, else None."""
+    slot = getattr(t, "_ndet_amax", None)
+    if slot is not None and getattr(t, "_ndet_amax_stamp", None) == _stamp(t):
+        return slot
+    return None
 
 
 def carry_amax(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
-    """``dst`` is a view / permutation / contiguous copy of ``src`` (same elements): it inherits the max |x| slot."""
-    slot = getattr(src, "_ndet_amax", None)
-    if slot is not None and getattr(src, "_ndet_amax_version", None) == src._version:
+    """``dst`` is a view / permutation / contiguous copy of ``src`` (same elements) made by this package: it inherits the max |x| slot."""
+    slot = _amax_tag(src)
+    if slot is not None:
         _tag_amax(dst, slot)
     return dst
 
@@ -98,16 +141,22 @@ def amax_value(slot: torch.Tensor) -> float:
     return float(slot.view(-1, 32)[:, 0].max())
 
 
+_slot_width_checked = False
+
+
 def amax_of(x: torch.Tensor) -> torch.Tensor:
     """The device slot holding max |x| of ``x``: left by the kernel that wrote it, or computed here in one pass."""
-    global amax_fallbacks
-    slot = getattr(x, "_ndet_amax", None)
-    if slot is None or getattr(x, "_ndet_amax_version", None) != x._version:
+    global amax_fallbacks, _slot_width_checked
+    if not _slot_width_checked:
+        assert _lib.load().ndet_amax_slot_floats() == _AmaxSlots.WIDTH, "amax slot width of the library differs from conv3d._AmaxSlots.WIDTH"
+        _slot_width_checked = True
+    slot = _amax_tag(x)
+    if slot is None:
         amax_fallbacks += 1
         slot = AMAX.take(x.device)
         st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         check(_lib.load().ndet_amax_f32(_ptr(x), x.numel(), _ptr(slot), st), "amax_f32")
-        _tag_amax(x, slot)
+        _tag_amax(x, slot, produced=False)
     return slot
 
 

@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(64 * (NCONS + 4), 1) void k_conv_split_wsp(const Co
                     for (int r = 0; r < 4; ++r) {
                         const int m = rowl + 16 * ta + r;
                         const int ow = m % p.OW, oh = (m / p.OW) % p.OH, od = m / (p.OW * p.OH);
-                        rrow[ta][r] = m < p.M ? (unsigned)((((int64_t)od * p.RH + (oh >> 1)) * p.RW + (ow >> 1)) * p.Cout * 4) : WS_OOB;
+                        rrow[ta][r] = m < p.M ? (unsigned)((((int64_t)od * p.RH + (oh >> 1)) * p.RW + (ow >> 1)) * p.Cout * 4) : WS_OOB;   // < 2^31 (launcher)
                     }
             }
 #pragma unroll
@@ -1363,7 +1363,9 @@ __global__ __launch_bounds__(64 * (NCONS + 4), 1) void k_conv_split_wsp(const Co
                     for (int r = 0; r < 4; ++r) {
                         if (!has_res) { rr[ta][r] = 0.0f; continue; }
                         if (p.res_up2) {
-                            rr[ta][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rres, rrow[ta][r] | (unsigned)(co * 4), 0, 0));
+                            // row offset PLUS column offset (Cout * 4 need not be a power of two: OR-ing them read Cout = 96 from the wrong place); rows past M keep
+                            // bit 31 set -- row offsets are below 2^31, so the sum cannot carry out of it -- and fall outside the descriptor
+                            rr[ta][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rres, rrow[ta][r] + (unsigned)(co * 4), 0, 0));
                         } else {
                             const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((16 * ta + r) * p.Cout * 4));
                             rr[ta][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rres, vo, so, 0));
@@ -1793,12 +1795,20 @@ static int split_launch_halo_any(const Conv3dParams& p, hipStream_t st, const ch
 #endif
 // Outputs of 32 MB and more (eight L2s of 4 MB: nothing of them is re-read from a cache) are written with non-temporal stores: the float4 copy
 // kernel of bench.py reaches 6.5 TB/s with them and 5.4 without, and the HBM-bound layers gain 3 - 12 % (l1.conv1 86 -> 75 us; the step 0.05 ms).
-// NDET_NT_BYTES in the environment moves the threshold (measurement runs).
-static int64_t conv_nt_bytes() {
-    static int64_t v = -1;
-    if (v < 0) { const char* e = getenv("NDET_NT_BYTES"); v = e ? atoll(e) : ((int64_t)32 << 20); }
-    return v;
+// Measurement runs move the threshold (and switch the order-2 deal off) through ndet_measurement_knob -- an explicit call, not the environment:
+// a stray variable in a production shell must not change what the production path launches.
+static int64_t g_nt_bytes = (int64_t)32 << 20;
+static bool g_order2 = true;
+static int64_t conv_nt_bytes() { return g_nt_bytes; }
+extern "C" int ndet_measurement_knob(const char* name, int64_t value) {
+    const char* fn = "ndet_measurement_knob";
+    NDET_REQUIRE(name, NDET_E_INVALID, "%s: null name", fn);
+    if (!strcmp(name, "nt_bytes")) { NDET_REQUIRE(value >= 0, NDET_E_INVALID, "%s: nt_bytes must be >= 0", fn); g_nt_bytes = value; return NDET_OK; }
+    if (!strcmp(name, "order2")) { NDET_REQUIRE(value == 0 || value == 1, NDET_E_INVALID, "%s: order2 is 0 or 1", fn); g_order2 = value != 0; return NDET_OK; }
+    ndet_set_error("%s: unknown knob '%s' (nt_bytes, order2)", fn, name);
+    return NDET_E_INVALID;
 }
+extern "C" int ndet_amax_slot_floats(void) { return NDET_AMAX_SUB * NDET_AMAX_STRIDE; }
 
 int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn) {
     p.direct = 0;
@@ -1822,8 +1832,7 @@ int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn)
             p.order = 0;
             if (!p.transposed && mt > 1 && nt * p.splits > 1 && save_w > save_a && w_bytes > (8 << 20)) p.order = 1;
             // the mirror case: weights small enough to sit in every L2 (1x1 layers), several column tiles, the rows re-read once per XCD otherwise
-            static const bool order2 = !getenv("NDET_NO_ORDER2");
-            if (order2 && p.order == 0 && !p.transposed && nt > 1 && mt >= 16 && w_bytes <= (2 << 20) && save_a >= (8 << 20) &&
+            if (g_order2 && p.order == 0 && !p.transposed && nt > 1 && mt >= 16 && w_bytes <= (2 << 20) && save_a >= (8 << 20) &&
                 (tile == 64 || tile == 128 || tile == 12864 || tile == 128256)) p.order = 2;
         }
     }

@@ -596,13 +596,18 @@ extern "C" int ndet_select_candidates_topk(int n_levels, const float* const* bes
     int cap = 0;
     for (int l = 0; l < n_levels; ++l)
         if (n[l] <= LDS_CAP && n[l] > cap) cap = n[l];
-    const size_t lds = (size_t)((cap + 3) / 4 * 4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the LDS limit is a per-device attribute of the kernel: raised once per device; where it cannot be raised (a device with 64 KB of LDS) the
+    // kernel takes every level's scores from global memory (cap = 0) instead of failing
+    static int attr_state[16] = {0};    // per device: 0 unknown, 1 raised, -1 refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (attr_state[dev] == 0) {
         hipError_t e = hipFuncSetAttribute((const void*)k_select_candidates_topk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_CAP * sizeof(float)));
-        NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
-        attr_set = true;
+        if (e != hipSuccess) (void)hipGetLastError();
+        attr_state[dev] = e == hipSuccess ? 1 : -1;
     }
+    if (attr_state[dev] < 0 && (size_t)((cap + 3) / 4 * 4) * sizeof(float) > 48 * 1024) cap = 0;
+    const size_t lds = (size_t)((cap + 3) / 4 * 4) * sizeof(float);
     hipLaunchKernelGGL(k_select_candidates_topk, dim3(1), dim3(1024), lds, (hipStream_t)stream, lv, score_thr, nms_pre, out_best, out_label, out_boxes,
                        counts, cap);
     NDET_CHECK_LAUNCH(fn);

@@ -86,32 +86,86 @@ def max_over_ranks(seconds: float, device=None) -> float:
     return float(t.item())
 
 
-def launch_local_ranks(script: str, argv: Sequence[str], n: int) -> int:
-    """``python script --gpus N`` without an external launcher: start the N ranks of one node as fresh child processes (the parent never
-    touches the GPU), 127.0.0.1 rendezvous on a free port, rank 0 inherits stdout.  The first rank that exits non-zero takes the others
-    down with it (they would wait in a collective forever); returns that exit code."""
+def _free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+        return s.getsockname()[1]
+
+
+def rank_affinity(local_rank: int, local_world: int, n_cpus: int = 0) -> dict:
+    """Host share of one rank when ``local_world`` ranks run on one node: a contiguous block of logical CPUs (``cpus``) and the thread cap for
+    torch's intra-op pool and the BLAS / OpenMP pools (``threads``).  Eight ranks each enqueue ~2.4 ms of launches per scene and run the numpy
+    camera products of hostmath.py; left alone, every rank's pools size themselves for the whole machine (256 logical CPUs on the MI355X hosts)
+    and the spinning workers of one rank delay the host syncs of the others (host-side findings)."""
+    if not n_cpus:
+        n_cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    local_world = max(1, local_world)
+    per = max(1, n_cpus // local_world)
+    first = (local_rank % local_world) * per
+    return dict(cpus=list(range(first, min(first + per, n_cpus))) or [local_rank % n_cpus], threads=max(1, min(16, per)))
+
+
+def apply_rank_affinity(local_rank: int, local_world: int) -> dict:
+    """Pin this process to its block of the CPUs it is allowed to run on and cap its thread pools (call before the first heavy torch op)."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    share = rank_affinity(local_rank, local_world, len(allowed))
+    cpus = [allowed[i] for i in share["cpus"] if i < len(allowed)]
+    if hasattr(os, "sched_setaffinity") and cpus and local_world > 1:
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError:
+            pass
+    torch.set_num_threads(share["threads"])
+    return dict(cpus=cpus, threads=share["threads"])
+
+
+def launch_local_ranks(script: str, argv: Sequence[str], n: int, timeout: float = 0.0) -> int:
+    """``python script --gpus N`` without an external launcher: start the N ranks of one node as fresh child processes (the parent never
+    touches the GPU), 127.0.0.1 rendezvous on a free port, rank 0 inherits stdout.  The first rank that exits non-zero takes the others
+    down with it (they would wait in a collective forever); returns that exit code.  The port is picked by binding port 0 and closed again
+    before rank 0 binds it: if somebody else took it in between (rank 0 reports EADDRINUSE), the launch is repeated on another port, three
+    times at most.  ``timeout`` > 0: ranks still running after that many seconds are killed and 124 is returned."""
+    import threading
     rc = 0
-    try:
-        while procs:
-            for p in list(procs):
-                code = p.poll()
-                if code is None:
-                    continue
-                procs.remove(p)
-                if code != 0:
-                    rc = rc or code
-                    for q in procs:
-                        q.terminate()
-            time.sleep(0.05)
-    finally:
-        for p in procs:
-            p.kill()
+    for attempt in range(3):
+        port = _free_port()
+        procs, tail = [], []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL,
+                                          stderr=subprocess.PIPE if r == 0 else None))
+
+        def tee(stream):     # rank 0's stderr passes through; its last lines are kept to recognise a lost port
+            for line in iter(stream.readline, b""):
+                sys.stderr.buffer.write(line)
+                sys.stderr.buffer.flush()
+                tail.append(line)
+                del tail[:-80]
+        th = threading.Thread(target=tee, args=(procs[0].stderr,), daemon=True)
+        th.start()
+        rc, t0, live = 0, time.monotonic(), list(procs)
+        try:
+            while live:
+                for p in list(live):
+                    code = p.poll()
+                    if code is None:
+                        continue
+                    live.remove(p)
+                    if code != 0:
+                        rc = rc or code
+                        for q in live:
+                            q.terminate()
+                if timeout and live and time.monotonic() - t0 > timeout:
+                    rc = rc or 124
+                    for q in live:
+                        q.kill()
+                time.sleep(0.05)
+        finally:
+            for p in live:
+                p.kill()
+        th.join(timeout=2.0)
+        lost_port = rc != 0 and any(b"EADDRINUSE" in l or b"ddress already in use" in l for l in tail)
+        if not lost_port:
+            break
     return rc

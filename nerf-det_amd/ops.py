@@ -170,6 +170,8 @@ def backproject_aggregate(features: Tensor, points: Tensor, projection: Tensor, 
         assert buf.is_contiguous() and buf.dtype == torch.float32 and vol.shape == (c, gx, gy, gz)
         assert count.shape == (1, gx, gy, gz) and count.dtype == torch.int64 and count.is_contiguous()
         out, layout = vol, (NDET_LAYOUT_NC if channels_last_out else NDET_LAYOUT_CN)
+        from .conv3d import note_raw_write
+        note_raw_write(vol)     # written through its raw pointer: any max |x| slot tagged on a tensor over this storage is stale from here on
     else:
         count = torch.empty((1, gx, gy, gz), dtype=torch.int64, device=f.device)
         if channels_last_out:
@@ -289,3 +291,43 @@ def sigma_head(h: Tensor, rows: Tensor, n_in: int, weight: Tensor, bias: Tensor,
     check(_lib.load().ndet_sigma_head(_ptr(h), ch, _ptr(rows), n_in, rows.shape[1], _ptr(w), _ptr(_f32c(bias)), n, _ptr(raw), _ptr(alpha),
                                       _stream(h)), "sigma_head")
     return (alpha, raw) if want_raw else alpha
+
+
+def point_mlp_alpha(points: Tensor, global_feat: Optional[Tensor], layers, w_sigma: Tensor, b_sigma: Tensor, want_raw: bool = False,
+                    want_h: bool = False):
+    """The whole density MLP in one launch (csrc/point_mlp_kernels.hip): encoder + concat, four Linear + ReLU layers with the activations
+    resident in LDS, sigma layer over [h | input], alpha.  nerf_mlp.py:80-90,138-144,181-197,224-227 + nerfdet.py:254-257.
+
+    ``points`` (3,N) / (3,X,Y,Z); ``global_feat`` (N,F) or None; ``layers`` = 4 x (fp16-pair planes, 1 / scale, bias) of the hidden layers
+    (conv3d.split_planes_f16 of conv3d.packed_linear, the first one padded to a multiple of 32 inputs).  Returns alpha (N) [, raw sigma (N)]
+    [, trunk output (N, 256)]."""
+    import ctypes
+    _need_gpu(points, global_feat, w_sigma, b_sigma)
+    pts = _f32c(points).reshape(3, -1)
+    n = pts.shape[1]
+    f = 0
+    if global_feat is not None:
+        global_feat = _f32c(global_feat)
+        assert global_feat.shape[0] == n
+        f = global_feat.shape[1]
+    k0 = (63 + f + 31) // 32 * 32
+    assert len(layers) == 4
+    hidden = layers[0][2].numel()
+    planes = (ctypes.c_void_p * 4)(*[l[0].data_ptr() for l in layers])
+    winv = (ctypes.c_float * 4)(*[float(l[1]) for l in layers])
+    biases = (ctypes.c_void_p * 4)(*[l[2].data_ptr() for l in layers])
+    for i, (pl, _, b) in enumerate(layers):
+        assert pl.numel() == (k0 if i == 0 else hidden) * 2 * hidden and b.numel() == hidden and b.dtype == torch.float32, "layer planes / bias of the wrong size"
+    ws = _f32c(w_sigma).reshape(-1)
+    assert ws.numel() == hidden + 63 + f
+    alpha = torch.empty((n,), dtype=torch.float32, device=pts.device)
+    raw = torch.empty((n,), dtype=torch.float32, device=pts.device) if want_raw else None
+    h = torch.empty((n, hidden), dtype=torch.float32, device=pts.device) if want_h else None
+    flops = 2 * n * (k0 * hidden + 3 * hidden * hidden + hidden + 63 + f)
+    nbytes = 4 * (3 * n + f * n + n) + 2 * 2 * hidden * (k0 + 3 * hidden)
+    trace.span("k_point_mlp/f16x2", lambda: check(
+        _lib.load().ndet_point_mlp_alpha(_ptr(pts), _ptr(global_feat), n, f, k0, hidden, planes, winv, biases, _ptr(ws), _ptr(_f32c(b_sigma)),
+                                         _ptr(raw), _ptr(alpha), _ptr(h), _stream(pts)), "point_mlp_alpha"),
+        flops=flops, bytes=nbytes, kind="conv")
+    out = (alpha,) + ((raw,) if want_raw else ()) + ((h,) if want_h else ())
+    return out if len(out) > 1 else alpha

@@ -138,12 +138,32 @@ class VanillaNeRFRadianceField(nn.Module):
         b = self.mlp.base
         n_in = 63 + global_feat.shape[1]
         width = (n_in + 31) // 32 * 32
+        out = self.mlp.sigma_layer.output_layer
+        if self.fused_ok(width):      # the shipped architecture: the whole chain in one launch, the 256-wide rows never leave the CU
+            return ops.point_mlp_alpha(points, global_feat, self._fused_layers(width), out.weight, out.bias)
         rows = ops.posenc_concat(points, global_feat, pad_to=width)
         h = rows
         for i, lin in enumerate(b.hidden_layers):
             h = linear_rows(h, packed_linear(lin, pad_in_to=width if i == 0 else 0), relu=1)
-        out = self.mlp.sigma_layer.output_layer
         return ops.sigma_head(h, rows, n_in, out.weight, out.bias)
+
+    FUSED_MLP = True     # csrc/point_mlp_kernels.hip (False: the layer-by-layer launches, kept for other widths and as the comparison in the tests)
+
+    def fused_ok(self, width: int) -> bool:
+        from . import conv3d
+        b = self.mlp.base
+        return (self.FUSED_MLP and conv3d.ARITHMETIC in ("f16x2", "bf16x3") and width <= 256 and b.hidden_layers[0].in_features <= width
+                and all(l.out_features == 256 for l in b.hidden_layers))
+
+    def _fused_layers(self, width: int):
+        """(fp16-pair planes, 1 / scale, bias) of the four hidden layers, cached with the packs (rebuilt when a parameter changes)."""
+        from .conv3d import packed_linear, split_planes_f16
+        layers = []
+        for i, lin in enumerate(self.mlp.base.hidden_layers):
+            pk = packed_linear(lin, pad_in_to=width if i == 0 else 0)
+            planes, winv = split_planes_f16(pk)
+            layers.append((planes, winv, pk["shift"]))
+        return layers
 
     def forward_rows_hip(self, x, condition, features):
         """Inference form of :meth:`forward` for the ray branch (A10, nerf_mlp.py:146-161,229-234): the dense layers of the trunk,

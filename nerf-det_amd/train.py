@@ -28,7 +28,7 @@ class DDPDetector(DistributedDataParallel):
 def wrap_ddp(model: torch.nn.Module, device: Optional[torch.device] = None, bucket_cap_mb: int = 128) -> DDPDetector:
     """config:185-186 (``find_unused_parameters=True``), tools/test.py:131-136 (``broadcast_buffers=False``).
 
-    ``bucket_cap_mb``: the 434 MB of fp32 gradients go out in 4 buckets instead of DDP's default 18 --
+    ``bucket_cap_mb``: the 433 MB of fp32 gradients go out in 4 buckets (:func:`ddp_bucket_plan`) instead of DDP's default 10 --
     xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring step is per-link bound, and fewer, larger messages amortise
     its 2(N-1) hops; the last bucket (the 3D neck, 77.6 M parameters, whose backward runs first) still overlaps the 2D
     backward."""
@@ -36,6 +36,18 @@ def wrap_ddp(model: torch.nn.Module, device: Optional[torch.device] = None, buck
     ids = None if device is None or device.type != "cuda" else [device.index if device.index is not None else torch.cuda.current_device()]
     return DDPDetector(model, device_ids=ids, find_unused_parameters=True, broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb,
                        gradient_as_bucket_view=True)
+
+
+def ddp_bucket_plan(model: torch.nn.Module, bucket_cap_mb: int = 128) -> list:
+    """Bytes per gradient bucket, in the order DDP reduces them (the reverse of ``model.parameters()``: the head's and the 3D neck's gradients are
+    ready first), from the same assignment routine DDP's constructor calls -- a small first bucket so that the all-reduce starts early, then
+    buckets that close once they have reached ``bucket_cap_mb``.  Printed by tools/bench_train.py on rank 0 and asserted in tests/test_ddp.py for the
+    shipped model: 433 MB of fp32 gradients -> 4 all-reduces (7 / 184 / 136 / 106 MB) instead of the default 25 MB cap's 10."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    first = getattr(dist, "_DEFAULT_FIRST_BUCKET_BYTES", 1024 * 1024)
+    idx, _ = dist._compute_bucket_assignment_by_size(list(reversed(params)), [first, bucket_cap_mb * 1024 * 1024], [False] * len(params))
+    rev = list(reversed(params))
+    return [sum(rev[i].numel() * rev[i].element_size() for i in bucket) for bucket in idx]
 
 
 FUSED_ADAMW = True     # torch's single-kernel-per-group AdamW when every parameter lives on the GPU (same update rule; ~100 launches fewer per step)

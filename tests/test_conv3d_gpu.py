@@ -260,6 +260,9 @@ WSP_CASES = [
     (256, 512, (1, 40, 52), 1, 1, 1, 1, 1, 129257),
     (64, 256, (1, 21, 30), 1, 1, 0, 2, 1, 129257),
     (128, 256, (1, 150, 200), 1, 1, 1, 1, 1, 129257),
+    (64, 96, (2, 21, 30), 1, 1, 1, 2, 1, 129256),       # upsampled residual with Cout * 4 NOT a power of two (row offset + column offset, not OR)
+    (64, 304, (1, 21, 30), 1, 1, 0, 2, 1, 129064),
+    (96, 96, (2, 13, 18), 1, 1, 1, 2, 1, 129257),
 ]
 
 

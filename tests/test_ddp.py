@@ -226,3 +226,19 @@ def test_bench_under_torch_distributed_run_uses_rccl(device):
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["collectives"].startswith("nccl") and line["value"] > 0 and line["median_ms"] > 0
+
+
+def test_ddp_bucket_plan_of_the_shipped_model():
+    """the bucket plan DDP builds for the 433 MB of fp32 gradients at train.wrap_ddp's 128 MB cap, computed with DDP's own
+    assignment routine on the real parameter list (DDP closes a bucket once it has reached the cap, so a bucket may exceed it by its last
+    tensor -- the 113 MB weight of the neck's 1024-channel 3x3x3 layer): 4 all-reduces of 7 / 184 / 136 / 106 MB, in the order the
+    gradients become ready (head and 3D neck first), where the default 25 MB cap gives 10.  Printed by tools/bench_train.py on rank 0."""
+    from nerfdet_amd.presets import build_nerfdet
+    from nerfdet_amd.train import ddp_bucket_plan
+    det = build_nerfdet(50)
+    plan = ddp_bucket_plan(det)
+    total = sum(p.numel() * 4 for p in det.parameters() if p.requires_grad)
+    assert sum(plan) == total and 400e6 < total < 470e6, total
+    mb = [round(b / 1e6) for b in plan]
+    assert len(plan) == 4 and mb[0] <= 8 and all(100 <= b <= 190 for b in mb[1:]), mb
+    assert len(ddp_bucket_plan(det, 25)) == 10                       # what the default cap would have cost

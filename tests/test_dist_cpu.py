@@ -101,3 +101,78 @@ def test_bench_launches_its_own_ranks(tmp_path):
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "tiny"],
                          env=dict(env, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""), capture_output=True, text=True, timeout=150)
     assert bad.returncode != 0 and "bench.py needs a GPU" in bad.stderr
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("script", ["bench.py", os.path.join("tools", "bench_train.py")])
+def test_eight_rank_dry_run_of_both_benchmarks(script):
+    """The driver's N = 8 launch, rehearsed on the CPU: ``python <script> --gpus 8 --dry-run`` starts its eight ranks
+    through nerfdet_amd.dist.launch_local_ranks, they rendezvous on 127.0.0.1 over gloo, every rank takes its own share of the host
+    (rank_affinity), and ONE JSON line with n_gpus = 8 comes back.  bench_train's dry run goes through the product's wrap_ddp /
+    build_optimizer / train_one_step and checks that the ranks hold identical parameters afterwards."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, script), "--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-run"],
+                         env=_clean_env(OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=360)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 3 and d["dry_run"] is True and d["value"] > 0
+    if "ddp_buckets_bytes" in d:
+        assert sum(d["ddp_buckets_bytes"]) == 4 * (64 * 256 + 256 + 256 * 1024 + 1024 + 1024 * 256 + 256 + 4 * 4 + 4)
+        assert len(d["ddp_buckets_bytes"]) >= 2 and d["rank_threads"] >= 1
+
+
+@pytest.mark.timeout(200)
+def test_a_rank_dying_in_the_barrier_ends_the_job_in_bounded_time():
+    """Rank 3 of 4 exits while the others wait in the closing barrier: the launcher takes them down and returns its exit code within seconds
+    (without that the job would sit in the collective until the driver's limit)."""
+    import subprocess
+    import sys
+    import time
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "0", "--dry-run"],
+                         env=_clean_env(NDET_DRYRUN_DIE_RANK="3", OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=180)
+    took = time.monotonic() - t0
+    assert out.returncode == 3, (out.returncode, out.stderr[-1500:])
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert took < 120, took
+
+
+def test_rank_affinity_partitions_the_host():
+    from nerfdet_amd import dist as D
+    shares = [D.rank_affinity(r, 8, 256) for r in range(8)]
+    assert [s["cpus"][0] for s in shares] == [32 * r for r in range(8)] and all(len(s["cpus"]) == 32 and s["threads"] == 16 for s in shares)
+    seen = [c for s in shares for c in s["cpus"]]
+    assert sorted(seen) == list(range(256))                       # disjoint, complete
+    assert D.rank_affinity(0, 1, 16) == dict(cpus=list(range(16)), threads=16)
+    assert D.rank_affinity(5, 8, 4)["threads"] == 1 and len(D.rank_affinity(5, 8, 4)["cpus"]) == 1     # fewer CPUs than ranks: still one each
+
+
+def test_launcher_retries_when_the_port_was_taken(tmp_path, monkeypatch):
+    """The free port is found by bind(0) and closed before rank 0 binds it; if somebody else took it meanwhile, rank 0 reports EADDRINUSE and
+    the launch is repeated on another port."""
+    import sys
+    from nerfdet_amd import dist as D
+    script = tmp_path / "rank.py"
+    marker = tmp_path / "attempts"
+    script.write_text(
+        "import os, sys\n"
+        f"p = {str(marker)!r}\n"
+        "n = int(open(p).read()) if os.path.exists(p) else 0\n"
+        "if os.environ['RANK'] == '0':\n"
+        "    open(p, 'w').write(str(n + 1))\n"
+        "    if n == 0:\n"
+        "        sys.stderr.write('RuntimeError: The server socket has failed to listen on any local network address. EADDRINUSE\\n')\n"
+        "        sys.exit(1)\n"
+        "print('ok')\n")
+    assert D.launch_local_ranks(str(script), [], 1) == 0
+    assert marker.read_text() == "2"

@@ -154,6 +154,59 @@ def test_f16x2_input_without_a_slot_takes_its_own_pass(device):
         assert C.amax_fallbacks == fb + 1 and torch.isfinite(y5).all() and not torch.equal(y4, y5)
 
 
+def test_f16x2_under_inference_mode(device):
+    """torch.inference_mode(): inference tensors keep no version counter (``t._version`` raises).  The library's own outputs still carry their
+    slot from layer to layer; a caller's tensor is never trusted there (torch could write it in place unseen): it takes a pass per call."""
+    from nerfdet_amd import conv3d as C
+    conv, bn = _layer(64, 128, 3, 1, 5)
+    conv2 = torch.nn.Conv3d(128, 64, 1, bias=False)
+    x = torch.randn(6, 10, 12, 64)
+    with torch.no_grad():
+        pk, pk2 = C.packed([conv.to(device)], bn.to(device)), C.packed([conv2.to(device)])
+        want = _run(C, "f16x2", _run(C, "f16x2", x.to(device), pk, None, 1, device), pk2, None, 0, device)
+    with torch.inference_mode():
+        xd = x.to(device)
+        assert xd.is_inference()
+        before = C.amax_fallbacks
+        y = _run(C, "f16x2", xd, pk, None, 1, device)
+        assert C.amax_fallbacks == before + 1 and not hasattr(xd, "_ndet_amax")       # the caller's tensor: a pass, no tag
+        z = _run(C, "f16x2", y, pk2, None, 0, device)
+        assert C.amax_fallbacks == before + 1                                          # the library's own output carried its slot
+        xd.mul_(2.0 ** 20)                                                             # unseen by any counter: the next call must still be right
+        y2 = _run(C, "f16x2", xd, pk, None, 1, device)
+        assert C.amax_fallbacks == before + 2 and torch.isfinite(y2).all()
+    assert torch.equal(z, want)
+
+
+def test_f16x2_raw_pointer_write_invalidates_the_slot(device):
+    """A kernel of the library refilling a caller-owned buffer (``out=``: the static volume of graphed.py) is invisible to torch's version
+    counter; the write is counted per storage, so a slot tagged before it -- on that tensor or on any view over the storage -- is stale."""
+    from nerfdet_amd import conv3d as C, ops
+    torch.manual_seed(3)
+    n_v, c, h, w, grid = 4, 64, 12, 16, (6, 6, 4)
+    from oracle import nerfdet_oracle as O
+    meta = O.ring_scene_meta(n_v, (4 * h, 4 * w))
+    proj = ops.compute_projection(meta, 4, device)
+    pts = ops.get_points(grid, (0.5, 0.5, 0.5), meta["lidar2img"]["origin"], device)
+    feats = torch.randn(n_v, c, h, w, device=device).contiguous(memory_format=torch.channels_last)
+    vol = torch.empty((*grid, c), device=device).permute(3, 0, 1, 2)
+    cnt = torch.empty((1, *grid), dtype=torch.int64, device=device)
+    conv = torch.nn.Conv3d(c, 64, 3, 1, 1, bias=False).to(device)
+    with torch.no_grad():
+        pk = C.packed([conv])
+        ops.backproject_aggregate(feats, pts, proj, out=(vol, cnt))
+        view = vol.permute(1, 2, 3, 0)
+        before = C.amax_fallbacks
+        y1 = _run(C, "f16x2", view, pk, None, 0, device)
+        y1b = _run(C, "f16x2", view, pk, None, 0, device)
+        assert C.amax_fallbacks == before + 1 and torch.equal(y1, y1b)                # tagged once, trusted while nothing wrote the storage
+        ops.backproject_aggregate(feats * 2.0 ** 20, pts, proj, out=(vol, cnt))       # same Python objects, new contents 2^20 times larger
+        y2 = _run(C, "f16x2", view, pk, None, 0, device)
+        assert C.amax_fallbacks == before + 2, "the refill through the raw pointer left a stale max |x| slot in use"
+        assert torch.isfinite(y2).all()
+        torch.testing.assert_close(y2, y1 * 2.0 ** 20, rtol=1e-5, atol=0)
+
+
 @pytest.mark.parametrize("cin,mid,cout,use_res", [(64, 64, 256, True), (128, 128, 512, True), (64, 64, 256, False)])
 def test_f16x2_chained_bottleneck(device, cin, mid, cout, use_res):
     """conv2 -> conv3 of a ResNet bottleneck in one launch: the intermediate's scale is the workgroup's own maximum."""

@@ -14,7 +14,7 @@ from test_fullsize_reference_cpu import check_against_reference, fullsize_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("arithmetic", ["bf16x3", "f32"])
+@pytest.mark.parametrize("arithmetic", ["f16x2", "bf16x3", "f32"])      # f16x2: the default arithmetic, held to the reference-generated fixture directly
 @pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg5slab"])
 def test_extract_volume_equals_reference_at_baseline_size(device, name, arithmetic):
     from nerfdet_amd import conv3d, ops

@@ -281,6 +281,87 @@ def test_sigma_mlp_on_matrix_cores_vs_oracle(device):
     torch.testing.assert_close(got.cpu(), ref.reshape(-1), rtol=0, atol=ATOL)
 
 
+def _mlp_fp64(mlp, pts, glob):
+    """The module's own forward in fp64 on the CPU: (raw sigma (N), trunk output (N, 256))."""
+    import copy
+    m = copy.deepcopy(mlp).double().cpu()
+    x = m.posi_encoder(pts.t().double())
+    rows = x if glob is None else torch.cat([x, glob.double()], dim=-1)
+    h = m.mlp.base(rows)                      # skip_layer 3: [relu(layer 3) | rows]
+    return m.mlp.sigma_layer(h).reshape(-1), h[:, :256]
+
+
+@pytest.mark.parametrize("n,f", [(5000, 70), (64, 70), (1, 70), (777, 0), (3001, 33)])
+def test_fused_point_mlp_against_fp64(device, n, f):
+    """csrc/point_mlp_kernels.hip: encoder + concat + 4 x (Linear + ReLU) + sigma layer + alpha in ONE launch, activations resident in LDS,
+    fp16-pair products with a PER-ROW activation scale.  Against the module evaluated in fp64 (nerf_mlp.py:80-90,138-144,181-197,224-227):
+    raw sigma within 2e-6 of each row's own magnitude, alpha within 1e-5 (north_star: 1e-4), the trunk output within 1e-5 of its row
+    maximum -- for ragged row counts (a last tile of 1 .. 63 rows), no conditioning at all, a conditioning width that is not the shipped one."""
+    from nerfdet_amd import ops
+    from nerfdet_amd.radiance_field import VanillaNeRFRadianceField
+    torch.manual_seed(n + f)
+    mlp = VanillaNeRFRadianceField(4, 256, 3, f, 1, 128)
+    with torch.no_grad():
+        for p in mlp.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    pts = torch.rand(3, n) * 6 - 3
+    glob = torch.randn(n, f) * torch.exp(torch.randn(n, 1)) if f else None
+    raw64, h64 = _mlp_fp64(mlp, pts, glob)
+    mlp.to(device)
+    width = (63 + f + 31) // 32 * 32
+    assert mlp.fused_ok(width)
+    out = mlp.mlp.sigma_layer.output_layer
+    with torch.no_grad():
+        alpha, raw, h = ops.point_mlp_alpha(pts.to(device), None if glob is None else glob.to(device), mlp._fused_layers(width), out.weight, out.bias,
+                                            want_raw=True, want_h=True)
+    raw, alpha, h = raw.cpu().double(), alpha.cpu().double(), h.cpu().double()
+    assert raw.shape == (n,) and h.shape == (n, 256)
+    rowmag = h64.abs().amax(1).clamp_min(1.0)
+    assert float(((h - h64).abs().amax(1) / rowmag).max()) <= 1e-5
+    assert float(((raw - raw64).abs() / (1.0 + raw64.abs())).max()) <= 2e-6 * 10
+    ref_alpha = 1 - torch.exp(-torch.relu(raw64))
+    assert float((alpha - ref_alpha).abs().max()) <= 1e-5
+    if n >= 1000:
+        assert 0.1 < float((ref_alpha > 0).double().mean()) < 1.0
+
+
+def test_fused_point_mlp_rows_of_unseen_voxels_do_not_disturb_their_neighbours(device):
+    """The reference's conditioning rows of voxels no view sees carry n_views * bias / 1e-8 ~ 1e9 (nerfdet.py:236-243) beside O(1) rows.  The
+    convolution kernels' per-TENSOR fp16-pair scale would leave the O(1) rows ~10 bits (why the point MLPs were pinned to
+    bf16x3); the fused kernel scales PER ROW: every row -- huge, ordinary, tiny -- keeps 2^-22 of its own magnitude, in the same tile."""
+    from nerfdet_amd import ops
+    from nerfdet_amd.radiance_field import VanillaNeRFRadianceField
+    torch.manual_seed(5)
+    mlp = VanillaNeRFRadianceField(4, 256, 3, 70, 1, 128)
+    with torch.no_grad():
+        for p in mlp.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    n = 640
+    pts = torch.rand(3, n) * 6 - 3
+    glob = torch.randn(n, 70)
+    glob[0::4] *= 1.0e9          # every tile of 64 rows mixes 1e9-rows, O(1) rows and 1e-6 rows
+    glob[1::4] *= 1.0e-6
+    raw64, h64 = _mlp_fp64(mlp, pts, glob)
+    mlp.to(device)
+    out = mlp.mlp.sigma_layer.output_layer
+    with torch.no_grad():
+        alpha, raw, h = ops.point_mlp_alpha(pts.to(device), glob.to(device), mlp._fused_layers(160), out.weight, out.bias, want_raw=True, want_h=True)
+        # the layer-by-layer launches on bf16x3 (the path the fused kernel replaces) for comparison
+        mlp.FUSED_MLP = False
+        try:
+            alpha_layers = mlp.alpha_from_points(pts.to(device), glob.to(device))
+        finally:
+            mlp.FUSED_MLP = True
+    rel = ((h.cpu().double() - h64).abs().amax(1) / h64.abs().amax(1).clamp_min(1e-30))
+    assert float(rel.max()) <= 1e-5, (float(rel[0::4].max()), float(rel[1::4].max()), float(rel[2::4].max()))
+    ref_alpha = 1 - torch.exp(-torch.relu(raw64))
+    assert float((alpha.cpu().double() - ref_alpha).abs().max()) <= 1e-5
+    assert float((alpha_layers.cpu().double() - ref_alpha).abs().max()) <= 1e-5
+    assert float(((raw.cpu().double() - raw64).abs() / (1.0 + raw64.abs())).max()) <= 2e-5
+
+
 @pytest.mark.parametrize("n_v,cm,hw,grid,vs", [(50, 32, (240, 320), (40, 40, 16), (0.16, 0.16, 0.2)), (101, 32, (120, 160), (20, 20, 9), (0.32, 0.32, 0.36)),
                                                (7, 8, (60, 80), (10, 6, 5), (0.6, 0.9, 0.6)), (3, 48, (48, 64), (9, 7, 3), (0.7, 0.7, 0.9))])
 def test_packed_density_features_equal_generic_kernel(device, n_v, cm, hw, grid, vs):

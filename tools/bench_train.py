@@ -24,6 +24,56 @@ def launch(args):
     return launch_local_ranks(__file__, sys.argv[1:], args.gpus)
 
 
+def dry_run(args):
+    """The launcher / rendezvous / DDP plumbing of this script without a GPU (tests/test_ddp.py): gloo, the package's own ``wrap_ddp`` +
+    ``build_optimizer`` + ``train_one_step`` around a small stand-in detector, per-rank CPU share, one JSON line from rank 0."""
+    from nerfdet_amd import dist as D
+    from nerfdet_amd.detector import BaseDetector
+    from nerfdet_amd.train import build_optimizer, ddp_bucket_plan, train_one_step, wrap_ddp
+    rank, world, local = D.init_dist("gloo")
+    share = D.apply_rank_affinity(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+
+    class Tiny(BaseDetector):          # train_step / _parse_losses are the product's; the network is a stand-in
+        def __init__(self):
+            super().__init__()
+            self.backbone = torch.nn.Linear(64, 256)
+            self.neck_3d = torch.nn.Sequential(torch.nn.Linear(256, 1024), torch.nn.ReLU(), torch.nn.Linear(1024, 256))
+            self.dead = torch.nn.Linear(4, 4)      # never used: find_unused_parameters=True must cope (SURVEY.md 0.2)
+
+        def forward(self, img, img_metas, return_loss=True):
+            y = self.neck_3d(torch.relu(self.backbone(img)))
+            return dict(loss_a=y.pow(2).mean(), loss_b=y.abs().mean())
+
+    torch.manual_seed(0)
+    det = Tiny()
+    grouped = torch.distributed.is_initialized()
+    model = wrap_ddp(det, None, bucket_cap_mb=1) if grouped else det
+    opt = build_optimizer(model)
+    g = torch.Generator().manual_seed(rank)
+    data = dict(img=torch.randn(8, 64, generator=g), img_metas=[{}])
+    for _ in range(args.warmup):
+        out = train_one_step(model, data, opt)
+    if grouped:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = train_one_step(model, data, opt)
+    if grouped:
+        torch.distributed.barrier()
+    dt = D.max_over_ranks((time.perf_counter() - t0) / args.steps)
+    w0 = det.backbone.weight.detach().clone()
+    if grouped:     # every rank must hold the same parameters after the all-reduced steps
+        ws = [torch.empty_like(w0) for _ in range(world)]
+        torch.distributed.all_gather(ws, w0)
+        assert all(torch.equal(ws[0], w) for w in ws), "ranks diverged: the gradients were not all-reduced"
+    if rank == 0:
+        print(json.dumps(dict(metric="dry-run", value=world / dt, unit="steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3,
+                              dry_run=True, log_vars=out["log_vars"], ddp_buckets_bytes=ddp_bucket_plan(det, 1), rank_threads=share["threads"],
+                              rank_cpus=len(share["cpus"]))))
+    if grouped:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -32,15 +82,19 @@ def main():
     ap.add_argument("--arith", default=None)
     ap.add_argument("--depth-supervise", type=int, default=1)
     ap.add_argument("--views", type=int, default=40)
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch(args))
+    if args.dry_run:
+        return dry_run(args)
     from nerfdet_amd import dist as D, rays, trace
     from nerfdet_amd.presets import build_nerfdet
     from nerfdet_amd.synth import batch_to, train_scene
     from nerfdet_amd.train import build_optimizer, train_one_step, wrap_ddp
     import nerfdet_amd.conv3d as C3
     rank, world, local = D.init_dist("nccl")
+    D.apply_rank_affinity(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     dev = torch.device("cuda", local)
     if args.arith:
         C3.set_arithmetic(args.arith)
@@ -93,6 +147,9 @@ def main():
                                          f"views, 40x40x16 voxels, 2048 rays x 64 samples, {'5' if args.depth_supervise else '4'} losses + backward + clip + AdamW"
                                          + (", DDP over RCCL" if grouped else ""), scenes_per_step=world),
                     log_vars=out["log_vars"], grad_norm=out.get("grad_norm"), peak_mem_GB=torch.cuda.max_memory_allocated() / 1e9)
+        if grouped:
+            from nerfdet_amd.train import ddp_bucket_plan
+            line["ddp_buckets_bytes"] = ddp_bucket_plan(det)
         if by_kernel:
             dom, (df, dms, dn) = max(by_kernel.items(), key=lambda kv: kv[1][1])
             tf = df / (dms * 1e-3) / 1e12

@@ -12,6 +12,14 @@ if len(sys.argv) > 2 and sys.argv[2] == "nochain":     # layer_times.py cfg2 noc
 if len(sys.argv) > 2 and sys.argv[2] in ("f16x2", "bf16x3", "bf16", "f32"):     # layer_times.py cfg2 f16x2
     from nerfdet_amd import conv3d
     conv3d.set_arithmetic(sys.argv[2])
+if "no_amax_commit" in sys.argv[2:]:     # layer_times.py cfg2 f16x2 no_amax_commit: DESIGN.md 11.2's measurement (every fp16-pair launch takes its own amax pass)
+    from nerfdet_amd import conv3d
+    conv3d.measurement_mode(no_amax_commit=True)
+for a in sys.argv[2:]:                    # layer_times.py cfg2 f16x2 nt_bytes=0 order2=0: library measurement knobs (ndet_measurement_knob)
+    if "=" in a:
+        from nerfdet_amd import _lib
+        k, v = a.split("=")
+        _lib.check(_lib.load().ndet_measurement_knob(k.encode(), int(v)), "measurement_knob")
 if os.environ.get("F16_MIN_KSTEPS"):
     from nerfdet_amd import conv3d
     conv3d.F16_MIN_KSTEPS = int(os.environ["F16_MIN_KSTEPS"])
