@@ -75,7 +75,7 @@ __device__ __forceinline__ float pm_input(int col, float px, float py, float pz,
 __global__ __launch_bounds__(256, 2) void k_point_mlp(const PointMlpParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t pm_lds[];
     constexpr int PL = PM_BM * PM_LDW;                     // one plane, fp16 elements
-    uint16_t* act = pm_lds;                                // [2][PM_BM][PM_LDW], 16-byte chunk index XORed with row & 7
+    uint16_t* act = pm_lds;                                // [2][PM_BM][PM_LDW], 16-byte chunk index XORed with row & 15 (16 rows of a fragment read sweep all 64 banks)
     float* fl = reinterpret_cast<float*>(pm_lds + 2 * PL);
     float* pmax = fl;                                      // [4][PM_BM]  per-wave partial row maxima of the layer being finished
     float* rinv = fl + 4 * PM_BM;                          // [PM_BM]     1 / (scale of the row's current operand planes)
@@ -87,35 +87,51 @@ __global__ __launch_bounds__(256, 2) void k_point_mlp(const PointMlpParams p) {
     const int row0 = blockIdx.x * PM_BM;
 
     // ---------------- phase 0: encoder + concat + per-row scale + split into the operand planes ----------------
+    // Four threads per row.  The conditioning values of a thread's quarter of the row are fetched as ONE batch of independent loads (statically
+    // indexed registers): fetched one by one inside a data-dependent loop they were 20 us of dependent L2 round trips per workgroup.
     {
-        const int r = tid >> 2, q = tid & 3;               // four threads per row, a quarter of the K0 columns each (a multiple of 8)
+        constexpr int CWMAX = PM_LDW / 4;
+        const int r = tid >> 2, q = tid & 3;
         const int n = row0 + r;
         const bool live = n < p.N;
         const int nn = live ? n : 0;
         const float px = live ? p.points[nn] : 0.0f, py = live ? p.points[p.N + nn] : 0.0f, pz = live ? p.points[2 * p.N + nn] : 0.0f;
         const float* grow = p.F ? p.glob + (int64_t)nn * p.F : p.points;
-        const int cw = p.K0 >> 2, c0 = q * cw;
+        const int cw = p.K0 >> 2, c0 = q * cw, cend = 63 + p.F;
+        float gv[CWMAX];
+#pragma unroll
+        for (int j = 0; j < CWMAX; ++j) {
+            const int c = c0 + j;
+            gv[j] = (live && j < cw && c >= 63 && c < cend) ? grow[c - 63] : 0.0f;
+        }
         // the row's maximum: coordinates, the encoder's terms (bounded by 1: the bound serves, the scale is a power of two anyway), conditioning
         float mx = fmaxf(fmaxf(fabsf(px), fabsf(py)), fmaxf(fabsf(pz), 1.0f));
-        if (live)
-            for (int c = max(c0, 63); c < min(c0 + cw, 63 + p.F); ++c) mx = fmaxf(mx, fabsf(grow[c - 63]));
+#pragma unroll
+        for (int j = 0; j < CWMAX; ++j) mx = fmaxf(mx, fabsf(gv[j]));
         mx = fmaxf(mx, __shfl_xor(mx, 1));
         mx = fmaxf(mx, __shfl_xor(mx, 2));
         const float s = conv_xscale_of(mx);
+        uint16_t* arow = act + r * PM_LDW;
+        auto put = [&](int c, float v) {                   // one element -> its (hi, lo) halves at (row r, column c)
+            const _Float16 h = (_Float16)(v * s);
+            const _Float16 l = (_Float16)(v * s - (float)h);
+            uint16_t* dst = arow + ((((c >> 3) ^ (r & 15))) << 3) + (c & 7);
+            dst[0] = __builtin_bit_cast(uint16_t, h);
+            dst[PL] = __builtin_bit_cast(uint16_t, l);
+        };
         float dot = 0.0f;
-        for (int c = c0; c < c0 + cw; c += 8) {
-            uint32_t hh[4], ll[4];
+        for (int c = q; c < 63; c += 4) {                  // the encoder's 63 columns, dealt over the row's four threads
+            const float v = live ? pm_input(c, px, py, pz, grow, 0) : 0.0f;
+            dot = fmaf(v, p.wsig[PM_HID + c], dot);
+            put(c, v);
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float a = live ? pm_input(c + 2 * j, px, py, pz, grow, p.F) : 0.0f;
-                const float b = live ? pm_input(c + 2 * j + 1, px, py, pz, grow, p.F) : 0.0f;
-                if (c + 2 * j < 63 + p.F) dot = fmaf(a, p.wsig[PM_HID + c + 2 * j], dot);
-                if (c + 2 * j + 1 < 63 + p.F) dot = fmaf(b, p.wsig[PM_HID + c + 2 * j + 1], dot);
-                pm_split2(a * s, b * s, hh[j], ll[j]);
+        for (int j = 0; j < CWMAX; ++j) {                  // conditioning columns (and the zero padding up to K0) of this thread's quarter
+            const int c = c0 + j;
+            if (j < cw && c >= 63) {
+                if (c < cend) dot = fmaf(gv[j], p.wsig[PM_HID + c], dot);
+                put(c, gv[j]);
             }
-            uint16_t* dst = act + r * PM_LDW + ((((c >> 3) ^ (r & 7))) << 3);
-            *reinterpret_cast<uint4*>(dst) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
-            *reinterpret_cast<uint4*>(dst + PL) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
         }
         dot += __shfl_xor(dot, 1);
         dot += __shfl_xor(dot, 2);
@@ -143,42 +159,50 @@ __global__ __launch_bounds__(256, 2) void k_point_mlp(const PointMlpParams p) {
             return reinterpret_cast<const pm_f16x8*>(wl + ((((int64_t)(ks >> 1) * 2 + pl) * PM_HID + chb + mt * 32 + frow) << 5) + (ks & 1) * 16 + fh * 8);
         };
         auto aptr = [&](int ks, int pl, int nt) -> const pm_f16x8* {
-            return reinterpret_cast<const pm_f16x8*>(act + pl * PL + (nt * 32 + frow) * PM_LDW + (((2 * ks + fh) ^ (frow & 7)) << 3));
+            return reinterpret_cast<const pm_f16x8*>(act + pl * PL + (nt * 32 + frow) * PM_LDW + (((2 * ks + fh) ^ (frow & 15)) << 3));
         };
-        pm_f16x8 fw[2][2][2];                               // [buffer][plane][mt]: the next slice's weights travel while this one multiplies
+        // Weight fragments come straight from L2 (~1 us away): the slices ks + 1 .. ks + 3 travel while slice ks multiplies (ring of four register
+        // sets, static indices through the 4-way unrolled walk); the activation fragments of slice ks + 1 are read from LDS under slice ks's MFMAs.
+        pm_f16x8 fw[4][2][2];                               // [ring slot][plane][mt]
+        pm_f16x8 fa[2][2][2];                               // [slot][plane][nt]
+        auto load_w = [&](int slot, int ks) {
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+            for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) fw[0][pl][mt] = *wptr(0, pl, mt);
+                for (int mt = 0; mt < 2; ++mt) fw[slot][pl][mt] = *wptr(ks, pl, mt);
+        };
+        auto load_a = [&](int slot, int ks) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) fa[slot][pl][nt] = *aptr(ks, pl, nt);
+        };
+        load_w(0, 0);
+        load_w(1, 1);
+        if (2 < nks) load_w(2, 2);
+        load_a(0, 0);
 #pragma unroll 1
-        for (int ks0 = 0; ks0 < nks; ks0 += 2) {
+        for (int ks0 = 0; ks0 < nks; ks0 += 4) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const int ks = ks0 + u;
-                if (ks + 1 < nks) {
+                if (ks < nks) {                             // (uniform: nks is 10 or 16 for the shipped widths)
+                    if (ks + 3 < nks) load_w((u + 3) & 3, ks + 3);
+                    if (ks + 1 < nks) load_a((u + 1) & 1, ks + 1);
+                    // smallest terms first: w_hi a_lo, w_lo a_hi, then w_hi a_hi
 #pragma unroll
-                    for (int pl = 0; pl < 2; ++pl)
+                    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) fw[u ^ 1][pl][mt] = *wptr(ks + 1, pl, mt);
+                        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[u][0][mt], fa[u & 1][1][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[u][1][mt], fa[u & 1][0][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[u][0][mt], fa[u & 1][0][nt], acc[mt][nt], 0, 0, 0);
                 }
-                pm_f16x8 fa[2][2];
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) fa[pl][nt] = *aptr(ks, pl, nt);
-                // smallest terms first: w_hi a_lo, w_lo a_hi, then w_hi a_hi
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[u][0][mt], fa[1][nt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[u][1][mt], fa[0][nt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[u][0][mt], fa[0][nt], acc[mt][nt], 0, 0, 0);
             }
         }
         // ---- epilogue: undo the scales, bias, ReLU; lane = row (nt, frow), registers = channels chb + 32 mt + 8 g + 4 fh + (0..3) ----
@@ -221,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void k_point_mlp(const PointMlpParams p) {
                         pm_split2(acc[mt][nt][4 * g] * s, acc[mt][nt][4 * g + 1] * s, h0, l0);
                         pm_split2(acc[mt][nt][4 * g + 2] * s, acc[mt][nt][4 * g + 3] * s, h1, l1);
                         const int chunk = ((chb + mt * 32) >> 3) + g;
-                        uint16_t* dst = act + row * PM_LDW + ((chunk ^ (row & 7)) << 3) + 4 * fh;
+                        uint16_t* dst = act + row * PM_LDW + ((chunk ^ (row & 15)) << 3) + 4 * fh;
                         *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
                         *reinterpret_cast<uint2*>(dst + PL) = make_uint2(l0, l1);
                     }
