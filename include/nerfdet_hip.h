@@ -162,12 +162,13 @@ int ndet_gather_detections(const int64_t* keep, int n_keep, const float* boxes, 
 /* The tail of get_bboxes without a host round trip (dense_heads/imvoxel_head_v2.py:216-285,528-555 + core/bbox/transforms.py:49-67):
  * greedy NMS (core/post_processing/box3d_nms.py:91-138) over the candidates ndet_select_candidates compacted -- their count is read
  * on the device from counts[n_levels] -- and the picks packed for ONE device-to-host copy: out_packed = {n_keep, n_candidates,
- * status, 0} followed by up to k_cap rows [x, y, z_bottom, dx, dy, dz, 0, score, label].  status != 0 (more than n_cap <= 4096
+ * status, range guard} followed by up to k_cap rows [x, y, z_bottom, dx, dy, dz, 0, score, label]; range_guard (may be null): the scene's guard word
+ * of ndet_conv_ndhwc_guarded, whose bit 0 is copied into the header so that it reaches the host with the picks.  status != 0 (more than n_cap <= 4096
  * candidates, a level with more than nms_pre survivors, more picks than rows): the caller repeats the scene on the synchronous
  * path.  workspace: ndet_nms_workspace_bytes(n_cap). */
 int ndet_nms_pack_detections(const float* cand_boxes, const float* cand_scores, const int64_t* cand_labels, const int* counts,
                              int n_levels, int nms_pre, int n_cap, float thresh, int64_t* keep, int64_t* n_keep, void* workspace,
-                             float* out_packed, int k_cap, void* stream);
+                             float* out_packed, int k_cap, const unsigned* range_guard, void* stream);
 
 /* A9. Samples along rays. Replaces sample_along_camera_ray(), mmdet3d/models/model_utils/render_ray.py:145-189
  * (inv_uniform=False).  ray_o, ray_d (R,3); t_rand NULL (det=True) or (R,S) uniforms in [0,1) -- the stream the
@@ -345,6 +346,28 @@ int ndet_conv_ndhwc_arith(const float* in, const uint16_t* w_planes, float* out,
                           const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
                           const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile, int arith,
                           const float* in_amax, float w_inv_scale, float* out_amax, void* workspace, void* stream);
+
+/* ndet_conv_ndhwc_arith with the RANGE GUARD of the fp16-pair arithmetic (arith 1; ignored otherwise).  The activation scale of that arithmetic
+ * is per tensor, so beside its fp32-class relative error an output carries an absolute floor of at most
+ *     2^-39 max|in| * guard_l1,      guard_l1 = max_j |scale_j| (sum_k |w_jk| + max|w| #{k: 0 < |w_jk| < 2^-16 max|w|})      (host, once per pack)
+ * whatever the distribution inside the tensor (csrc/conv_common.hpp::conv_guard_check).  max|in| is known on the device at kernel entry: when
+ * the floor exceeds guard_tol the launch ORs 1 into *guard (device word, zeroed by the caller per scene).  The caller reads the word with the
+ * detections (ndet_nms_pack_detections) and repeats such a scene on the six-product bf16x3 arithmetic.  Same reference modules as
+ * ndet_conv_ndhwc_split (mmdet3d/models/necks/imvoxelnet.py:36-67,233-260, dense_heads/imvoxel_head_v2.py:45-49, the backbone behind
+ * detectors/nerfdet.py:140); the tensor that first needed it: the sigma-MLP rows of nerfdet.py:236-243. */
+int ndet_conv_ndhwc_guarded(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
+                            const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
+                            const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile, int arith,
+                            const float* in_amax, float w_inv_scale, float* out_amax, void* workspace, float guard_l1, float guard_tol,
+                            unsigned* guard, void* stream);
+
+/* ndet_conv_chain_arith with the range guard (see ndet_conv_ndhwc_guarded): guard_l1 belongs to w_planes and max|in|, guard_l1_3 to w3_planes and
+ * each workgroup's own maximum of the intermediate.  The bottleneck tail of the backbone called at mmdet3d/models/detectors/nerfdet.py:140. */
+int ndet_conv_chain_guarded(const float* in, const uint16_t* w_planes, int D, int H, int W, int Cin, int Cmid, const int* kernel,
+                            const int* stride, const int* pad, const float* scale1, const float* shift1, const uint16_t* w3_planes,
+                            int Cout, const float* scale3, const float* shift3, const float* residual, int relu3, float* out,
+                            int arith, const float* in_amax, float w1_inv_scale, float w3_inv_scale, float* out_amax, float guard_l1,
+                            float guard_l1_3, float guard_tol, unsigned* guard, void* stream);
 
 /* ndet_conv_chain_split with the arithmetic as an argument (as above; w1_inv_scale / w3_inv_scale belong to w_planes / w3_planes).  In the
  * fp16-pair arithmetic the intermediate's scale is the workgroup's own maximum: it never exists as a whole tensor.  Same reference code

@@ -55,6 +55,10 @@ SIGNATURES = {
     "ndet_split_weights_bf16x3": ([_P, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_split_weights_f16x2": ([_P, c_int, c_int, c_int, c_float, _P, _P], c_int),
     "ndet_conv_ndhwc_arith": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P, _P], c_int),
+    "ndet_conv_ndhwc_guarded": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P,
+                                 c_float, c_float, _P, _P], c_int),
+    "ndet_conv_chain_guarded": ([_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_float, c_float, _P,
+                                 c_float, c_float, c_float, _P, _P], c_int),
     "ndet_amax_f32": ([_P, ctypes.c_int64, _P, _P], c_int),
     "ndet_amax_slot_floats": ([], c_int),
     "ndet_point_mlp_alpha": ([_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
@@ -68,7 +72,7 @@ SIGNATURES = {
     "ndet_select_candidates": ([c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P], c_int),
     "ndet_select_candidates_topk": ([c_int, _P, _P, _P, _P, c_float, c_int, _P, _P, _P, _P, _P], c_int),
     "ndet_gather_detections": ([_P, c_int, _P, _P, _P, _P, _P, _P, _P], c_int),
-    "ndet_nms_pack_detections": ([_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, c_int, _P], c_int),
+    "ndet_nms_pack_detections": ([_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, c_int, _P, _P], c_int),
     "ndet_normalize_views": ([_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P], c_int),
     "ndet_target_rays": ([_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
     "ndet_stem_pack_weights": ([_P, _P, _P], c_int),

@@ -160,6 +160,57 @@ def amax_of(x: torch.Tensor) -> torch.Tensor:
     return slot
 
 
+# ---- range guard of the fp16-pair arithmetic (csrc/conv_common.hpp::conv_guard_check) ----
+# Every fp16-pair launch compares its absolute error floor, 2^-39 max|in| * guard_l1, with GUARD_TOL on the device and raises the scene's guard
+# word when it is exceeded.  The detector zeroes the word at the start of a scene (guard_begin), the word reaches the host with the scene's
+# detections (head.simple_test_fused: header word 3 of the packed picks, no extra copy or sync), and a scene whose word is set is repeated on the
+# six-product bf16x3 arithmetic, whose operands are exact (detector.simple_test).  Other callers read it with guard_tripped() (synchronises).
+GUARD_ENABLED = True
+GUARD_TOL = 2.0 ** -15        # absolute; north_star's bar is 1e-4 on O(1) voxel features: a third of it, for the floors of a few layers in a row
+guard_trips = 0               # scenes repeated on bf16x3 because their guard word was set (diagnostic)
+_GUARD_WORDS = {}
+
+
+def guard_word(device) -> Optional[torch.Tensor]:
+    """The guard word (int32, on the device) of the current stream, or None when the guard is off."""
+    if not GUARD_ENABLED:
+        return None
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    w = _GUARD_WORDS.get(key)
+    if w is None:
+        w = _GUARD_WORDS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
+
+
+def guard_begin(device) -> None:
+    """Start of a scene: clear the current stream's guard word (stream-ordered before the scene's launches)."""
+    w = guard_word(device)
+    if w is not None:
+        w.zero_()
+
+
+def guard_tripped(device) -> bool:
+    """Has a fp16-pair launch on the current stream exceeded the tolerance since guard_begin?  (synchronises; the detector does not use this)"""
+    w = guard_word(device)
+    return bool(w is not None and int(w.item()) & 1)
+
+
+def guard_l1(pk: dict) -> float:
+    """max over output channels j of |scale_j| (sum_k |w_jk| + max|w| #{k: 0 < |w_jk| < 2^-16 max|w|}): what the launch multiplies 2^-39 max|in|
+    by to bound its absolute error floor (the second term: weights so far below the weight maximum that THEIR error is absolute).  Once per pack."""
+    hit = pk.get("guard_l1")
+    if hit is None:
+        w = pk["w"].abs()
+        wmax = w.max()
+        tiny = ((w > 0) & (w < wmax * 2.0 ** -16)).sum(dim=(0, 2)).float()
+        l1 = w.sum(dim=(0, 2)) + wmax * tiny
+        if pk.get("scale") is not None:
+            l1 = l1 * pk["scale"].abs()
+        v = float(l1.max())
+        hit = pk["guard_l1"] = v if math.isfinite(v) else float("inf")
+    return hit
+
+
 launch_hook = None  # bench.py: callable(flops, thunk, kernel_name) wrapping every MFMA-conv launch (event timing); None = direct
 
 KERNEL_NAMES = {("bf16x3", 64): "k_conv_split<64,64,2,2>", ("bf16x3", 128): "k_conv_split<128,128,2,2>", ("bf16x3", 12864): "k_conv_split<128,64,2,2>",
@@ -330,10 +381,13 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
     else:
         planes, winv, in_amax = split_planes(pk), 1.0, None
     out_amax = AMAX.take(x.device) if want_amax else None
-    _launch(flops, lambda: check(lib.ndet_conv_ndhwc_arith(_ptr(x), _ptr(planes), _ptr(out), d, h, w, pk["cin"], pk["cout"], i3(kernel), i3(stride), i3(pad),
-                                                           int(transposed), _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), int(residual_up2), relu,
-                                                           splits, tile, 1 if arith == "f16x2" else 0, _ptr(in_amax), winv, _ptr(out_amax), _ptr(ws), st),
-                                 "conv_ndhwc_arith"), arith, tile, nbytes)
+    gw = guard_word(x.device) if arith == "f16x2" else None
+    gl1 = guard_l1(pk) if gw is not None else 0.0
+    _launch(flops, lambda: check(lib.ndet_conv_ndhwc_guarded(_ptr(x), _ptr(planes), _ptr(out), d, h, w, pk["cin"], pk["cout"], i3(kernel), i3(stride), i3(pad),
+                                                             int(transposed), _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), int(residual_up2), relu,
+                                                             splits, tile, 1 if arith == "f16x2" else 0, _ptr(in_amax), winv, _ptr(out_amax), _ptr(ws),
+                                                             gl1, GUARD_TOL, _ptr(gw), st),
+                                 "conv_ndhwc_guarded"), arith, tile, nbytes)
     if want_amax:
         _tag_amax(out, out_amax)
     return out
@@ -547,9 +601,12 @@ def conv2d_chain_nhwc(x: torch.Tensor, pk: dict, pk3: dict, residual: Optional[t
         (p1, w1inv), (p3, w3inv) = split_planes_f16(pk), split_planes_f16(pk3)
         in_amax, out_amax = amax_of(x), (None if NO_AMAX_COMMIT else AMAX.take(x.device))
         name += "/f16x2"
-        thunk = lambda: check(lib.ndet_conv_chain_arith(_ptr(x), _ptr(p1), n, h, w, cin, mid, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw), _ptr(pk["scale"]),
-                                                        _ptr(pk["shift"]), _ptr(p3), cout, _ptr(pk3["scale"]), _ptr(pk3["shift"]), _ptr(residual), relu,
-                                                        _ptr(out), 1, _ptr(in_amax), w1inv, w3inv, _ptr(out_amax), st), "conv_chain_arith")
+        gw = guard_word(x.device)
+        gl1, gl3 = (guard_l1(pk), guard_l1(pk3)) if gw is not None else (0.0, 0.0)
+        thunk = lambda: check(lib.ndet_conv_chain_guarded(_ptr(x), _ptr(p1), n, h, w, cin, mid, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw), _ptr(pk["scale"]),
+                                                          _ptr(pk["shift"]), _ptr(p3), cout, _ptr(pk3["scale"]), _ptr(pk3["shift"]), _ptr(residual), relu,
+                                                          _ptr(out), 1, _ptr(in_amax), w1inv, w3inv, _ptr(out_amax), gl1, gl3, GUARD_TOL, _ptr(gw), st),
+                              "conv_chain_guarded")
         if out_amax is not None:
             _tag_amax(out, out_amax)
     else:

@@ -42,7 +42,26 @@ struct Conv3dParams {
     int nt = 0;                       // 1: the output is written with non-temporal stores (set by the launcher for outputs that cannot stay in the caches)
     float* amax_out = nullptr;        // any arithmetic, optional: max |out| is atomically maxed into the slot at amax_out (1 KiB, zeroed by the caller
                                       // before the launch) -- the next layer's amax_in without another pass over the tensor
+    // range guard of the fp16-pair arithmetic (conv_guard_check below)
+    unsigned* guard = nullptr;        // device word, bit 0 raised when this launch's absolute error floor exceeds guard_tol (null: no check)
+    float guard_l1 = 0.0f;            // max over output channels j of |scale_j| (sum_k |w_jk| + wmax #{k: 0 < |w_jk| < 2^-16 wmax})
+    float guard_tol = 0.0f;           // absolute tolerance the floor is compared with
 };
+
+// ---- range guard of the fp16-pair arithmetic ----
+// The activation scale is per TENSOR: an element keeps a relative error of 2^-22 only while it lies within 2^-16 of the tensor's maximum; below
+// that its error is absolute, <= 2^-39 amax (fp16's subnormal spacing under the scale).  An output y_j = scale_j sum_k w_jk a_k therefore carries,
+// beside the fp32-class relative term 2^-22 sum |w||a|, an ABSOLUTE floor of at most
+//         2^-39 amax_in |scale_j| sum_k |w_jk|          (+ the same for the few weights below 2^-16 of the weight maximum: folded into guard_l1)
+// however the magnitudes are distributed inside the tensor.  For activations of ordinary size the floor is far below any tolerance (amax 1e3,
+// ||w||_1 30: 5e-8); it becomes visible when a tensor's maximum is ~1e6 and more -- the sigma-MLP rows of voxels no view sees (1e9, nerfdet.py:236-243),
+// a saturated image region, a BatchNorm-folded outlier channel.  Nothing has to guess which tensor that is: amax_in is on the device at kernel
+// entry, so workgroup 0 compares the floor with the tolerance and raises a flag that travels to the host with the detections' status word
+// (nerfdet_amd/detector.py re-runs such a scene on the six-product bf16x3 arithmetic, whose operands are exact).
+__device__ __forceinline__ void conv_guard_check(const Conv3dParams& p, float amax_in) {
+    if (p.guard && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && amax_in * p.guard_l1 * 0x1p-39f > p.guard_tol)
+        atomicOr(p.guard, 1u);
+}
 
 // ---- the amax slot of a tensor: 8 sub-slots, one per XCD, each in a 128-byte line of its own (256 floats = 1 KiB per slot) ----
 // The L2s of the eight XCDs are kept coherent line by line: a line that workgroups on different XCDs update (atomics or stores) migrates

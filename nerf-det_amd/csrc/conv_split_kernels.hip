@@ -314,6 +314,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (uni_min_wgs<BM, BN, SCH>())) void 
     f32x16 acc[MT][NT];
     int ztap;
     const float amax_in = conv_amax_in(p);
+    conv_guard_check(p, amax_in);
     conv_split_mainloop<BM, BN, WGM, WGN, SCH>(p, wsplit, lds16, acc, ztap);
     const float osc = conv_oscale_of(p, amax_in);
 
@@ -417,6 +418,7 @@ struct ConvChain {
     float* out;            // (M, Cout3)
     int Cout3;
     int relu3;             // 0 none, 1 ReLU last, 2 ReLU before the residual add
+    float guard_l1 = 0.0f; // range guard (Conv3dParams::guard_l1) of W3
 };
 
 #ifndef CHAIN64_F16_WGS
@@ -442,6 +444,7 @@ __global__ __launch_bounds__(256, MID == 64 ? (SCH == 1 ? CHAIN64_F16_WGS : 3) :
     f32x16 acc[MT][NT];
     int ztap;
     const float amax_in = conv_amax_in(p);
+    conv_guard_check(p, amax_in);
     conv_split_mainloop<BM, BN, WGM, WGN, SCH>(p, wsplit, lds16, acc, ztap);
     const float osc = conv_oscale_of(p, amax_in);
 
@@ -473,6 +476,8 @@ __global__ __launch_bounds__(256, MID == 64 ? (SCH == 1 ? CHAIN64_F16_WGS : 3) :
         ymax = fmaxf(fmaxf(wg_max[0], wg_max[1]), fmaxf(wg_max[2], wg_max[3]));
         ys = conv_xscale_of(ymax);
         osc3 = conv_xinv_of(ymax) * c.w3inv;
+        // range guard of the chained GEMM: its operand scale is this workgroup's own maximum, so is its floor (conv_guard_check)
+        if (p.guard && tid == 0 && ymax * c.guard_l1 * 0x1p-39f > p.guard_tol) atomicOr(p.guard, 1u);
     }
     float omax = 0.0f;
     // ---- the intermediate's split, into LDS as the A operand of the chained GEMM ----
@@ -848,6 +853,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_split_ws(const Conv3dParams p, 
     const ConvBlock blk = conv_block(p);
     const int m0 = blk.x * WS_BM, n0 = blk.y * WS_BN;
     const float amax_in = conv_amax_in(p);
+    conv_guard_check(p, amax_in);
     const int stid = tid & 255;
     const int akq = stid & 7, arow_ = stid >> 3;
     const int bkg = stid & 3, brow_ = stid >> 2;
@@ -1143,6 +1149,7 @@ __global__ __launch_bounds__(64 * (NCONS + 4), 1) void k_conv_split_wsp(const Co
     const bool consumer = wave < NCONS;
     const float xs = SCH == 1 ? conv_xscale(p.amax_in) : 1.0f;
     const float osc = conv_oscale(p);
+    if (SCH == 1) conv_guard_check(p, conv_amax_in(p));
     float mx = 0.0f;
     const int wm = (wave % NCONS) / CW, wn = (wave % NCONS) % CW;
 
@@ -1496,6 +1503,7 @@ __global__ __launch_bounds__(64 * (2 * WGN + NPROD), 1) void k_conv_split_halo(c
     const int pdi = pb / g.nph;
     const int d0 = pdi << g.ltd, h0 = phi << g.lth, w0 = pwi << g.ltw;
     const float amax_in = conv_amax_in(p);
+    conv_guard_check(p, amax_in);
 
     const int nch_all = p.Cin / CBK;
     int cb = 0, ce = nch_all;
@@ -1977,6 +1985,22 @@ extern "C" int ndet_conv_ndhwc_bf16(const float* in, const uint16_t* w_planes, f
                             residual_up2, relu, splits, tile, workspace, stream);
 }
 
+struct ConvGuard { unsigned* flag; float l1, l1_3, tol; };
+static thread_local ConvGuard g_guard = {nullptr, 0.0f, 0.0f, 0.0f};     // handed from the *_guarded entry points to the shared argument checks below (per call)
+
+extern "C" int ndet_conv_ndhwc_guarded(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
+                                       const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
+                                       const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile, int arith,
+                                       const float* in_amax, float w_inv_scale, float* out_amax, void* workspace, float guard_l1, float guard_tol,
+                                       unsigned* guard, void* stream) {
+    NDET_REQUIRE(!guard || (guard_l1 >= 0.0f && guard_tol > 0.0f), NDET_E_INVALID, "ndet_conv_ndhwc_guarded: the guard needs guard_l1 >= 0 and guard_tol > 0");
+    g_guard = ConvGuard{arith == 1 ? guard : nullptr, guard_l1, 0.0f, guard_tol};
+    const int rc = ndet_conv_ndhwc_arith(in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, transposed, scale, shift, residual, residual_up2, relu, splits,
+                                         tile, arith, in_amax, w_inv_scale, out_amax, workspace, stream);
+    g_guard = ConvGuard{nullptr, 0.0f, 0.0f, 0.0f};
+    return rc;
+}
+
 extern "C" int ndet_conv_ndhwc_arith(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
                                      const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
                                      const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile, int arith,
@@ -2034,6 +2058,7 @@ static int conv_split_entry(const char* fn, int max_order, const float* in_amax,
     p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
     p.max_order = max_order;
     p.amax_in = in_amax; p.winv = w_inv_scale; p.amax_out = out_amax;
+    p.guard = g_guard.flag; p.guard_l1 = g_guard.l1; p.guard_tol = g_guard.tol;
     if (transposed) {
         for (int a = 0; a < 3; ++a)
             NDET_REQUIRE(kernel[a] == 2 && stride[a] == 2 && pad[a] == 0, NDET_E_UNSUPPORTED, "%s: transposed conv supports kernel 2 stride 2 pad 0 only", fn);
@@ -2092,6 +2117,19 @@ extern "C" int ndet_conv_chain_arith(const float* in, const uint16_t* w_planes, 
                                      int Cout, const float* scale3, const float* shift3, const float* residual, int relu3, float* out,
                                      int arith, const float* in_amax, float w1_inv_scale, float w3_inv_scale, float* out_amax, void* stream);
 
+extern "C" int ndet_conv_chain_guarded(const float* in, const uint16_t* w_planes, int D, int H, int W, int Cin, int Cmid, const int* kernel,
+                                       const int* stride, const int* pad, const float* scale1, const float* shift1, const uint16_t* w3_planes,
+                                       int Cout, const float* scale3, const float* shift3, const float* residual, int relu3, float* out,
+                                       int arith, const float* in_amax, float w1_inv_scale, float w3_inv_scale, float* out_amax, float guard_l1,
+                                       float guard_l1_3, float guard_tol, unsigned* guard, void* stream) {
+    NDET_REQUIRE(!guard || (guard_l1 >= 0.0f && guard_l1_3 >= 0.0f && guard_tol > 0.0f), NDET_E_INVALID, "ndet_conv_chain_guarded: the guard needs l1 >= 0 and tol > 0");
+    g_guard = ConvGuard{arith == 1 ? guard : nullptr, guard_l1, guard_l1_3, guard_tol};
+    const int rc = ndet_conv_chain_arith(in, w_planes, D, H, W, Cin, Cmid, kernel, stride, pad, scale1, shift1, w3_planes, Cout, scale3, shift3, residual, relu3, out,
+                                         arith, in_amax, w1_inv_scale, w3_inv_scale, out_amax, stream);
+    g_guard = ConvGuard{nullptr, 0.0f, 0.0f, 0.0f};
+    return rc;
+}
+
 extern "C" int ndet_conv_chain_split(const float* in, const uint16_t* w_planes, int D, int H, int W, int Cin, int Cmid, const int* kernel,
                                      const int* stride, const int* pad, const float* scale1, const float* shift1, const uint16_t* w3_planes,
                                      int Cout, const float* scale3, const float* shift3, const float* residual, int relu3, float* out,
@@ -2121,6 +2159,7 @@ extern "C" int ndet_conv_chain_arith(const float* in, const uint16_t* w_planes, 
     p.in = in; p.w = reinterpret_cast<const float*>(w_planes); p.out = nullptr; p.scale = scale1; p.shift = shift1; p.res = nullptr; p.partial = nullptr;
     p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cmid; p.relu = 1; p.max_order = max_order;
     p.amax_in = in_amax; p.winv = w1_inv_scale;
+    p.guard = g_guard.flag; p.guard_l1 = g_guard.l1; p.guard_tol = g_guard.tol;
     for (int a = 0; a < 3; ++a)
         NDET_REQUIRE(kernel[a] >= 1 && kernel[a] <= 7 && stride[a] >= 1 && stride[a] <= 4 && pad[a] >= 0 && pad[a] < kernel[a], NDET_E_UNSUPPORTED,
                      "%s: kernel/stride/pad out of range on axis %d", fn, a);
@@ -2138,7 +2177,7 @@ extern "C" int ndet_conv_chain_arith(const float* in, const uint16_t* w_planes, 
     p.splits = 1; p.res_up2 = 0; p.RH = p.RW = 0;
     ConvChain c;
     c.w3 = w3_planes; c.scale3 = scale3; c.shift3 = shift3; c.res = residual; c.out = out; c.Cout3 = Cout; c.relu3 = relu3;
-    c.w3inv = arith == 1 ? w3_inv_scale : 1.0f; c.amax_out = out_amax;
+    c.w3inv = arith == 1 ? w3_inv_scale : 1.0f; c.amax_out = out_amax; c.guard_l1 = g_guard.l1_3;
     p.nt = (int64_t)p.M * Cout * 4 >= conv_nt_bytes() ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     int rc;

@@ -237,7 +237,8 @@ extern "C" int ndet_aligned_3d_nms(const float* boxes, const float* scores, cons
 __global__ __launch_bounds__(256) void k_pack_detections(const int64_t* __restrict__ keep, const int64_t* __restrict__ n_keep,
                                                          const int* __restrict__ counts, int n_levels, int nms_pre, int n_cap, int k_cap,
                                                          const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                         const int64_t* __restrict__ labels, float* __restrict__ out) {
+                                                         const int64_t* __restrict__ labels, float* __restrict__ out,
+                                                         const unsigned* __restrict__ range_guard) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = counts[n_levels];
     const int k = n > n_cap ? 0 : (int)*n_keep;
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(256) void k_pack_detections(const int64_t* __restri
             for (int l = 0; l < n_levels; ++l)
                 if (counts[l] > nms_pre) status |= 2;
         if (k > k_cap) status |= 4;
-        out[0] = (float)k; out[1] = (float)n; out[2] = (float)status; out[3] = 0.0f;
+        // header word 3: the scene's range-guard word (conv_common.hpp::conv_guard_check) rides to the host with the picks -- no extra copy, no sync
+        out[0] = (float)k; out[1] = (float)n; out[2] = (float)status; out[3] = range_guard ? (float)(*range_guard & 1u) : 0.0f;
     }
     if (i >= k || i >= k_cap) return;
     const int64_t c = keep[i];
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void k_pack_detections(const int64_t* __restri
 
 extern "C" int ndet_nms_pack_detections(const float* cand_boxes, const float* cand_scores, const int64_t* cand_labels, const int* counts,
                                         int n_levels, int nms_pre, int n_cap, float thresh, int64_t* keep, int64_t* n_keep, void* workspace,
-                                        float* out_packed, int k_cap, void* stream) {
+                                        float* out_packed, int k_cap, const unsigned* range_guard, void* stream) {
     const char* fn = "ndet_nms_pack_detections";
     NDET_REQUIRE(cand_boxes && cand_scores && cand_labels && counts && keep && n_keep && workspace && out_packed, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(n_levels >= 1 && n_levels <= 4 && n_cap >= 1 && n_cap <= NMS_MAX && k_cap >= 1, NDET_E_INVALID, "%s: bad sizes", fn);
@@ -276,7 +278,7 @@ extern "C" int ndet_nms_pack_detections(const float* cand_boxes, const float* ca
     hipLaunchKernelGGL(k_nms_mask, dim3(words, words), dim3(64), 0, st, cand_boxes, cand_labels, order, 0, thresh, mask, n_dev, n_cap);
     hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, st, mask, order, 0, keep, n_keep, n_dev, n_cap);
     hipLaunchKernelGGL(k_pack_detections, dim3((k_cap + 255) / 256), dim3(256), 0, st, keep, n_keep, counts, n_levels, nms_pre, n_cap, k_cap, cand_boxes,
-                       cand_scores, cand_labels, out_packed);
+                       cand_scores, cand_labels, out_packed, range_guard);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }

@@ -18,7 +18,7 @@ void ndet_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int ndet_version(void) { return 105; }
+extern "C" int ndet_version(void) { return 106; }
 extern "C" const char* ndet_last_error(void) { return g_err; }
 
 #define VOX_PER_TILE 16  // one workgroup = 4 waves x 4 voxels = 16 consecutive voxels (one z column at Z=16)

@@ -192,7 +192,23 @@ class nerfdet(BaseDetector):
         rb = self._ray_batch(kwargs)
         return self.simple_test(img, img_metas, ray_batch=rb or None)
 
+    def _repeat_exact(self, img, img_metas, depth, ray_batch, evaluate_nerf):
+        """A scene whose range-guard word came back set (a fp16-pair launch saw max|in| * ||w||_1 * 2^-39 above conv3d.GUARD_TOL: its per-tensor
+        scale left part of a tensor with an absolute error that could show): once more on the six-product bf16x3 arithmetic, whose operands are
+        exact whatever their range."""
+        from . import conv3d
+        conv3d.guard_trips += 1
+        prev = conv3d.set_arithmetic("bf16x3")
+        try:
+            return self.simple_test(img, img_metas, depth, ray_batch, evaluate_nerf, defer=False)
+        finally:
+            conv3d.set_arithmetic(prev)
+
     def simple_test(self, img, img_metas, depth=None, ray_batch=None, evaluate_nerf=False, defer=False):
+        from . import conv3d
+        guarded = conv3d.ARITHMETIC == "f16x2" and img.is_cuda
+        if guarded:
+            conv3d.guard_begin(img.device)
         x, valids, _, rgb_preds, _ = self.extract_feat(img, img_metas, "test", depth, ray_batch)
         if evaluate_nerf:
             # nerfdet.py:342-343 computes (psnr, ssim, rmse) with save_rendered_img and drops them; kept here for the caller, without the PNGs
@@ -210,7 +226,15 @@ class nerfdet(BaseDetector):
                 bbox_list = lambda: ready
         if defer:
             pending = bbox_list
-            return lambda: [bbox3d2result(b, s, l) for b, s, l in pending()]
+
+            def finish():
+                got = pending()
+                if guarded and getattr(got, "range_guard", False):
+                    return self._repeat_exact(img, img_metas, depth, ray_batch, evaluate_nerf)
+                return [bbox3d2result(b, s, l) for b, s, l in got]
+            return finish
+        if guarded and (getattr(bbox_list, "range_guard", False) or (not hasattr(bbox_list, "range_guard") and conv3d.guard_tripped(img.device))):
+            return self._repeat_exact(img, img_metas, depth, ray_batch, evaluate_nerf)
         res = [bbox3d2result(b, s, l) for b, s, l in bbox_list]
         trace.mark("head_nms")
         return res

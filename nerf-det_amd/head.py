@@ -14,7 +14,7 @@ from torch import nn
 
 from . import losses  # noqa: F401  (registers the loss types the head builds)
 from . import ops
-from .conv3d import carry_amax, conv3d_ndhwc, packed, to_ndhwc
+from .conv3d import carry_amax, conv3d_ndhwc, guard_tripped, guard_word, packed, to_ndhwc
 from .nms import aligned_3d_nms
 from .registry import HEADS, build_loss
 
@@ -28,6 +28,12 @@ class Scale(nn.Module):
 
     def forward(self, x):
         return x * self.scale
+
+
+class Detections(list):
+    """``[(boxes, scores, labels)]`` of one scene plus the scene's range-guard word (conv3d.guard_word): True when a fp16-pair launch of the
+    scene reported an absolute error floor above conv3d.GUARD_TOL -- the detector repeats such a scene on the bf16x3 arithmetic."""
+    range_guard = False
 
 
 def compute_centerness(t):
@@ -248,14 +254,17 @@ class ScanNetImVoxelHeadV2(nn.Module):
                 return [(meta["box_type_3d"](o_box, origin=(0.5, 0.5, 0.5), box_dim=6, with_yaw=False), o_sc, o_lab)]
 
             def fast(host):
-                """The packed picks on the host -> detections; None when the device-side tail flagged an overflow (status != 0)."""
+                """The packed picks on the host -> detections; None when the device-side tail flagged an overflow (status != 0).  Header word 3
+                is the scene's range-guard word (conv3d.guard_word): it rides on the returned list as ``range_guard``."""
                 k, status = int(host[0]), int(host[2])
                 if status != 0:
                     return None
                 rows = host[4:4 + k * 9].view(k, 9)
                 b = object.__new__(DepthInstance3DBoxes)
                 b.tensor, b.box_dim, b.with_yaw = rows[:, :7].contiguous(), 7, False
-                return [(b, rows[:, 7].contiguous(), rows[:, 8].to(torch.int64))]
+                dets = Detections([(b, rows[:, 7].contiguous(), rows[:, 8].to(torch.int64))])
+                dets.range_guard = bool(int(host[3]) & 1)
+                return dets
 
             # ---- fast tail: the per-level top-nms_pre cut, the NMS (candidate count read on the device) and the packing of the picks for
             # ONE device-to-host copy, all enqueued behind the neck's kernels: no host round trip inside the post-processing ----
@@ -272,10 +281,12 @@ class ScanNetImVoxelHeadV2(nn.Module):
                                  torch.empty((max(int(lib.ndet_nms_workspace_bytes(n_cap)), 8),), dtype=torch.uint8, device=dev))
                 keep, n_keep, ws = bufs[key]
                 packed_out = torch.empty((4 + k_cap * 9,), dtype=torch.float32, device=dev)
+                gw = guard_word(dev)
                 check(lib.ndet_nms_pack_detections(c_void_p(c_box.data_ptr()), c_void_p(c_best.data_ptr()), c_void_p(c_lab.data_ptr()),
                                                    c_void_p(counts.data_ptr()), nl, int(self.test_cfg.nms_pre), n_cap, float(self.test_cfg.iou_thr),
                                                    c_void_p(keep.data_ptr()), c_void_p(n_keep.data_ptr()), c_void_p(ws.data_ptr()),
-                                                   c_void_p(packed_out.data_ptr()), k_cap, st), "nms_pack_detections")
+                                                   c_void_p(packed_out.data_ptr()), k_cap, c_void_p(0 if gw is None else gw.data_ptr()), st),
+                      "nms_pack_detections")
                 if defer:
                     # every handle owns its pinned landing buffer + event until it is collected: a scene queued on the same stream before
                     # the previous handle's finish() ran must not overwrite that scene's picks.  Collected pairs return to a free list.
@@ -292,14 +303,16 @@ class ScanNetImVoxelHeadV2(nn.Module):
                             free.append(pin)
                             if got is None:
                                 with torch.cuda.stream(stream):
-                                    got = general()
+                                    got = Detections(general())
+                                    got.range_guard = guard_tripped(dev)
                             state["res"] = got
                         return state["res"]
                     return finish
                 got = fast(packed_out.cpu())                                  # the one host sync of the scene
                 if got is not None:
                     return got
-            res = general()
+            res = Detections(general())
+            res.range_guard = guard_tripped(dev)           # (the host-driven tail has synchronised already)
             return (lambda: res) if defer else res
         # generic path: per-level top-k, then threshold, NMS, box conversion with library ops
         for i in range(nl):

@@ -289,3 +289,69 @@ def test_detections_agree_between_the_two_fp32_class_arithmetics(device):
     assert torch.equal(a["labels_3d"], b["labels_3d"])
     torch.testing.assert_close(a["scores_3d"], b["scores_3d"], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(a["boxes_3d"].tensor, b["boxes_3d"].tensor, rtol=1e-4, atol=1e-4)
+
+
+def test_range_guard_trips_exactly_when_the_floor_exceeds_the_tolerance(device):
+    """csrc/conv_common.hpp::conv_guard_check: a fp16-pair launch compares 2^-39 max|in| guard_l1 with conv3d.GUARD_TOL on the device.  Ordinary
+    activations leave the word clear; the same layer on an input whose maximum is 1e9 (the sigma-MLP's unseen-voxel rows, nerfdet.py:236-243)
+    raises it -- and there the result really is outside the elementwise bar the guard protects, while bf16x3 is inside it."""
+    from nerfdet_amd import conv3d as C
+    torch.manual_seed(11)
+    conv, bn = _layer(64, 128, 3, 1, 5)
+    x = torch.relu(torch.randn(6, 10, 12, 64))
+    ref = _reference(conv, bn, x, None, 1)
+    with torch.no_grad():
+        pk = C.packed([conv.to(device)], bn.to(device))
+        l1 = C.guard_l1(pk)
+        w = pk["w"].abs().cpu() * pk["scale"].abs().cpu()[None, :, None]
+        assert abs(l1 - float(w.sum(dim=(0, 2)).max())) <= 1e-4 * l1          # no weight of this layer lies 2^-16 below the weight maximum
+        C.guard_begin(device)
+        y = _run(C, "f16x2", x, pk, None, 1, device)
+        assert not C.guard_tripped(device)
+        assert _rel_rms(y, ref) < 1e-6
+        # a few rows 1e9 times larger: every other row now lies 2^-30 below the tensor's maximum
+        xb = x.clone()
+        xb[0, 0, :3] *= 1.0e9
+        refb = _reference(conv, bn, xb, None, 1)
+        C.guard_begin(device)
+        yb = _run(C, "f16x2", xb, pk, None, 1, device)
+        assert C.guard_tripped(device), "max|in| 1e9 x ||w||_1 x 2^-39 is far above the tolerance: the word must be set"
+        far = torch.ones(6, 10, 12, dtype=torch.bool)
+        far[:2, :2, :5] = False                                                       # outputs the huge rows do not reach (3x3x3 taps)
+        err_f16 = float((yb.cpu().double() - refb)[far].abs().max())
+        C.guard_begin(device)
+        y3 = _run(C, "bf16x3", xb, pk, None, 1, device)
+        assert not C.guard_tripped(device)                                            # the exact-operand arithmetic has no floor to report
+        err_b3 = float((y3.cpu().double() - refb)[far].abs().max())
+        assert err_b3 <= 1e-4 and err_f16 > 10 * err_b3, (err_f16, err_b3)            # what the guard is there to catch
+        # the threshold itself: scale the input so that the floor sits just below / just above the tolerance
+        amax = float(x.abs().max())
+        for factor, want in ((0.5, False), (2.0, True)):
+            s = factor * C.GUARD_TOL * 2.0 ** 39 / (l1 * amax)
+            C.guard_begin(device)
+            _run(C, "f16x2", x * s, pk, None, 1, device)
+            assert C.guard_tripped(device) == want, (factor, s)
+
+
+def test_range_guard_of_the_chained_bottleneck_uses_the_workgroups_own_maximum(device):
+    from nerfdet_amd import conv3d as C
+    torch.manual_seed(12)
+    c2 = nn.Conv2d(64, 64, 3, 1, 1, bias=False); b2 = nn.BatchNorm2d(64).eval()
+    c3 = nn.Conv2d(64, 256, 1, bias=False); b3 = nn.BatchNorm2d(256).eval()
+    x = torch.relu(torch.randn(2, 24, 32, 64))
+    with torch.no_grad():
+        for m in (c2, b2, c3, b3):
+            m.to(device)
+        pk2, pk3 = C.packed([c2], b2), C.packed([c3], b3)
+        prev = C.set_arithmetic("f16x2")
+        try:
+            C.guard_begin(device)
+            C.conv2d_chain_nhwc(x.to(device), pk2, pk3, relu=1)
+            assert not C.guard_tripped(device)
+            b2.weight.mul_(3.0e7)                       # the INTERMEDIATE becomes huge (a BatchNorm-folded outlier), the input stays ordinary
+            pk2 = C.packed([c2], b2)
+            C.guard_begin(device)
+            C.conv2d_chain_nhwc(x.to(device), pk2, pk3, relu=1)
+            assert C.guard_tripped(device)
+        finally:
+            C.set_arithmetic(prev)

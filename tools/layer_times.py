@@ -27,9 +27,9 @@ if os.environ.get("TIMING_NO_AMAX_OUT"):      # timing probe only (results are g
     from ctypes import c_void_p
     from nerfdet_amd import _lib
     _l = _lib.load()
-    _f, _g = _l.ndet_conv_ndhwc_arith, _l.ndet_conv_chain_arith
-    _l.ndet_conv_ndhwc_arith = lambda *a: _f(*a[:22], c_void_p(0), *a[23:])
-    _l.ndet_conv_chain_arith = lambda *a: _g(*a[:23], c_void_p(0), *a[24:])
+    _f, _g = _l.ndet_conv_ndhwc_guarded, _l.ndet_conv_chain_guarded
+    _l.ndet_conv_ndhwc_guarded = lambda *a: _f(*a[:22], c_void_p(0), *a[23:])
+    _l.ndet_conv_chain_guarded = lambda *a: _g(*a[:23], c_void_p(0), *a[24:])
 dev = torch.device("cuda")
 det = bench.build_model(w).to(dev)
 batch = bench.to_device(bench.synth_batch(w, 0), dev)
