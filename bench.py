@@ -551,6 +551,7 @@ def main():
             "execution": "hipGraph replay (2 graphs) + eager K1 + eager post-processing" if args.graph else "eager launches",
             "stages_ms": stages,
             "detections_last_step": int(len(res[0]["scores_3d"])),
+            "range_guard_trips": C3.guard_trips,      # scenes repeated on bf16x3 because a fp16-pair launch reported a visible absolute error floor (expected: 0)
         }
         if serving is not None:
             out["serving_two_scenes_in_flight"] = {
