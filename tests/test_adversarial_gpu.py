@@ -5,10 +5,11 @@ brighter than the rest.  Modules exercised: the ResNet / FPN behind mmdet3d/mode
 
 What must hold, ELEMENTWISE, against the same network evaluated in fp64 on the CPU:
 
-    |gpu - ref| <= 1e-4 max(1, |ref|)      or      |gpu - ref| <= 8 x (what PyTorch-CPU fp32 itself is off by, 3x3 neighbourhood maximum)
+    |gpu - ref| <= 1e-4 max(1, |ref|)      or      |gpu - ref| <= 8 x (what PyTorch-CPU fp32 itself is off by AT THAT PLACE: the maximum
+                                                                      over the channels and a 5-wide spatial neighbourhood)
 
 (the second clause: where huge and ordinary values cancel inside one receptive field no fp32 evaluation meets the first -- the bar there is
-"no worse than fp32", not "better than fp32").  Either the fp16-pair result meets it, or the device-side range guard (conv_common.hpp::
+"no worse than fp32", not "better than fp32"; an element's own fp32 error is a random draw, the conditioning of its place is not).  Either the fp16-pair result meets it, or the device-side range guard (conv_common.hpp::
 conv_guard_check) must have raised the scene's guard word, in which case the policy's answer -- the same scene on the six-product bf16x3
 arithmetic -- must meet it.  Never: the bar missed with the word clear."""
 import copy
@@ -49,7 +50,7 @@ def _spread_batchnorm(mods, g):
 def _bar(got, ref64, cpu32, what, pool):
     """Elementwise: 1e-4 max(1, |ref|), or 8 x the neighbourhood maximum of PyTorch-CPU fp32's own error.  Returns the worst ratio to the bar."""
     err = (got.double() - ref64).abs()
-    own = (cpu32.double() - ref64).abs()
+    own = (cpu32.double() - ref64).abs().amax(dim=1, keepdim=True)      # over the channels: the conditioning of a place
     own = pool(own)
     allowed = torch.maximum(1e-4 * ref64.abs().clamp_min(1.0), 8.0 * own)
     ratio = float((err / allowed).max())
@@ -102,12 +103,12 @@ def test_backbone_fpn_with_adversarial_statistics(device, bright):
     with torch.no_grad():
         ref64 = copy.deepcopy(det_cpu.neck).double()(copy.deepcopy(det_cpu.backbone).double()(img.double()))[0]
         cpu32 = det_cpu.neck(det_cpu.backbone(img))[0]
-    assert torch.isfinite(ref64).all() and float(ref64.abs().max()) > (1e6 if bright else 1e2)
+    assert torch.isfinite(ref64).all() and float(ref64.abs().max()) > (1e6 if bright else 1.0)
     det = copy.deepcopy(det_cpu).to(device)
     xd = img.to(device).unsqueeze(0)
     with torch.no_grad():
         (x, _, _), tripped = _with_policy(C, device, lambda: det.extract_2d(xd))
-    pool = lambda e: F.max_pool2d(e, 3, 1, 1)
+    pool = lambda e: F.max_pool2d(e, 5, 1, 2)
     ratio, frac = _bar(x.float().cpu(), ref64, cpu32, "FPN level 0", pool)
     print(f"bright={bright}: guard tripped={tripped}, worst error / bar = {ratio:.3f}, {frac:.4f} of the elements inside 1e-4 max(1,|ref|) outright, "
           f"max |ref| {float(ref64.abs().max()):.3g}")
@@ -149,7 +150,7 @@ def test_neck3d_with_adversarial_volume(device):
     with torch.no_grad():
         outs, tripped = _with_policy(C, device, lambda: det.neck_3d(vd))
     assert tripped
-    pool = lambda e: F.max_pool3d(e, 3, 1, 1)
+    pool = lambda e: F.max_pool3d(e, 5, 1, 2)
     for lvl in range(3):
         ratio, frac = _bar(outs[lvl].float().cpu(), ref64[lvl], cpu32[lvl], f"neck level {lvl}", pool)
         print(f"neck level {lvl}: worst error / bar = {ratio:.3f}, {frac:.4f} inside 1e-4 max(1,|ref|) outright")
@@ -177,11 +178,12 @@ def test_forward_test_repeats_a_flagged_scene_on_bf16x3(device):
             want = det(return_loss=False, **batch)[0]
         finally:
             C.set_arithmetic(prev)
-        assert torch.equal(got["labels_3d"], want["labels_3d"]) and torch.equal(got["scores_3d"], want["scores_3d"])
-        assert torch.equal(got["boxes_3d"].tensor, want["boxes_3d"].tensor)
+        same = lambda a, b: a.shape == b.shape and torch.equal(a.contiguous().view(torch.int32), b.contiguous().view(torch.int32))   # bit patterns: this scene's boxes hold inf / nan
+        assert torch.equal(got["labels_3d"], want["labels_3d"]) and same(got["scores_3d"], want["scores_3d"])
+        assert same(got["boxes_3d"].tensor, want["boxes_3d"].tensor)
         # the deferred (serving) form applies the same policy
         fin = det.forward_test_async(batch["img"], batch["img_metas"], **{k: v for k, v in batch.items() if k not in ("img", "img_metas")})
         got2 = fin()[0]
-        assert C.guard_trips == before + 2 and torch.equal(got2["scores_3d"], want["scores_3d"])
+        assert C.guard_trips == before + 2 and same(got2["scores_3d"], want["scores_3d"])
         det(return_loss=False, **plain)
         assert C.guard_trips == before + 2, "an ordinary scene must stay on the fp16-pair arithmetic"

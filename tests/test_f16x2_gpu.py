@@ -299,7 +299,11 @@ def test_range_guard_trips_exactly_when_the_floor_exceeds_the_tolerance(device):
     torch.manual_seed(11)
     conv, bn = _layer(64, 128, 3, 1, 5)
     x = torch.relu(torch.randn(6, 10, 12, 64))
-    ref = _reference(conv, bn, x, None, 1)
+    xb = x.clone()
+    xb[0, 0, :3] *= 1.0e9         # a few rows 1e9 times larger: every other row then lies 2^-30 below the tensor's maximum
+    with torch.no_grad():
+        ref = _reference(conv, bn, x, None, 1)
+        refb = _reference(conv, bn, xb, None, 1)
     with torch.no_grad():
         pk = C.packed([conv.to(device)], bn.to(device))
         l1 = C.guard_l1(pk)
@@ -309,10 +313,6 @@ def test_range_guard_trips_exactly_when_the_floor_exceeds_the_tolerance(device):
         y = _run(C, "f16x2", x, pk, None, 1, device)
         assert not C.guard_tripped(device)
         assert _rel_rms(y, ref) < 1e-6
-        # a few rows 1e9 times larger: every other row now lies 2^-30 below the tensor's maximum
-        xb = x.clone()
-        xb[0, 0, :3] *= 1.0e9
-        refb = _reference(conv, bn, xb, None, 1)
         C.guard_begin(device)
         yb = _run(C, "f16x2", xb, pk, None, 1, device)
         assert C.guard_tripped(device), "max|in| 1e9 x ||w||_1 x 2^-39 is far above the tolerance: the word must be set"
