@@ -369,6 +369,20 @@ int ndet_conv_chain_guarded(const float* in, const uint16_t* w_planes, int D, in
                             int arith, const float* in_amax, float w1_inv_scale, float w3_inv_scale, float* out_amax, float guard_l1,
                             float guard_l1_3, float guard_tol, unsigned* guard, void* stream);
 
+/* A whole ResNet bottleneck of stage 1 in one launch, fp16-pair arithmetic: out = relu(bn3(W3 . relu(bn2(conv3x3(relu(bn1(W1 . x)))))) + identity),
+ * identity = x (Cin == Cout) or, with wd_planes, bnD(WD . x) (the first block of the stage; Cin = 64) -- mmdet's Bottleneck.forward (style 'pytorch',
+ * stride 1) behind mmdet3d/models/detectors/nerfdet.py:140.  x (N, H, W, Cin) channels-last, out (N, H, W, Cout); the intermediate has 64 channels
+ * (w1 (1, Cin/32, 2, 64, 32), w2 (9, 2, 2, 64, 32), w3 (1, 2, 2, Cout, 32), wd (1, Cin/32, 2, Cout, 32): ndet_split_weights_f16x2 planes with their
+ * inverse scales; scale* / shift*: folded eval-mode BatchNorm).  A workgroup owns a 4 x 16 patch of one map from x to out: conv1 is evaluated on
+ * the patch plus its one-pixel halo into LDS, conv2's taps multiply out of that image, conv3 follows as in ndet_conv_chain_arith; the scales of
+ * the two intermediates are the workgroup's own maxima.  in_amax: x's slot; out_amax (may be null): max |out|.  guard (may be null): the range
+ * guard word (see ndet_conv_ndhwc_guarded), guard_l1_host = 4 HOST floats (w1, w2, w3, wd). */
+int ndet_bottleneck_f16x2(const float* x, int N, int H, int W, int Cin, int Cout, const uint16_t* w1_planes, float w1_inv_scale, const float* scale1,
+                          const float* shift1, const uint16_t* w2_planes, float w2_inv_scale, const float* scale2, const float* shift2,
+                          const uint16_t* w3_planes, float w3_inv_scale, const float* scale3, const float* shift3, const uint16_t* wd_planes,
+                          float wd_inv_scale, const float* scale_d, const float* shift_d, const float* in_amax, float* out_amax, float* out,
+                          const float* guard_l1_host, float guard_tol, unsigned* guard, void* stream);
+
 /* ndet_conv_chain_split with the arithmetic as an argument (as above; w1_inv_scale / w3_inv_scale belong to w_planes / w3_planes).  In the
  * fp16-pair arithmetic the intermediate's scale is the workgroup's own maximum: it never exists as a whole tensor.  Same reference code
  * as ndet_conv_chain_split: the bottleneck tail of the backbone called at mmdet3d/models/detectors/nerfdet.py:140. */

@@ -59,6 +59,8 @@ SIGNATURES = {
                                  c_float, c_float, _P, _P], c_int),
     "ndet_conv_chain_guarded": ([_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_float, c_float, _P,
                                  c_float, c_float, c_float, _P, _P], c_int),
+    "ndet_bottleneck_f16x2": ([_P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P, _P, c_float, _P, _P, _P, c_float, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
+                               _P, c_float, _P, _P], c_int),
     "ndet_amax_f32": ([_P, ctypes.c_int64, _P, _P], c_int),
     "ndet_amax_slot_floats": ([], c_int),
     "ndet_point_mlp_alpha": ([_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P], c_int),

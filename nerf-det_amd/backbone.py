@@ -11,7 +11,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .conv3d import bn_relu_maxpool_nhwc, carry_amax, chain_ok, conv2d_chain_nhwc, conv2d_nhwc, packed, stem_conv_bn_relu_maxpool, stem_ok
+from .conv3d import (bn_relu_maxpool_nhwc, bottleneck_ok, carry_amax, chain_ok, conv2d_bottleneck_nhwc, conv2d_chain_nhwc, conv2d_nhwc, packed,
+                     stem_conv_bn_relu_maxpool, stem_ok)
 from .conv_train import conv_bn_act, conv_forward
 from .registry import BACKBONES, NECKS
 
@@ -45,9 +46,12 @@ class Bottleneck(nn.Module):
     def forward_nhwc(self, x):
         """Inference form on (N,H,W,C): every conv carries its frozen BatchNorm, ReLU and (last one) the residual
         add in the MFMA kernel's epilogue -- 4 kernels instead of 4 convs + 10 elementwise passes."""
-        y = conv2d_nhwc(x, packed([self.conv1], self.bn1), relu=1)
-        idt = x if self.downsample is None else conv2d_nhwc(x, packed([self.downsample[0]], self.downsample[1]), amax=False)
-        pk2, pk3 = packed([self.conv2], self.bn2), packed([self.conv3], self.bn3)
+        pk1, pk2, pk3 = packed([self.conv1], self.bn1), packed([self.conv2], self.bn2), packed([self.conv3], self.bn3)
+        pkd = None if self.downsample is None else packed([self.downsample[0]], self.downsample[1])
+        if bottleneck_ok(x, pk1, pk2, pk3, pkd):          # stage 1: the whole block in one launch, the 64-channel intermediates never leave the CU
+            return conv2d_bottleneck_nhwc(x, pk1, pk2, pk3, pkd)
+        y = conv2d_nhwc(x, pk1, relu=1)
+        idt = x if pkd is None else conv2d_nhwc(x, pkd, amax=False)
         if chain_ok(pk2, pk3):          # stages 1 / 2: the 64- / 128-channel intermediate never leaves the CU
             return conv2d_chain_nhwc(y, pk2, pk3, residual=idt, relu=1)
         y = conv2d_nhwc(y, pk2, relu=1)

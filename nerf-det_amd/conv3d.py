@@ -621,6 +621,60 @@ def conv2d_chain_nhwc(x: torch.Tensor, pk: dict, pk3: dict, residual: Optional[t
     return out
 
 
+FUSE_BOTTLENECKS = True     # the whole stage-1 bottleneck (conv1 -> conv2 -> conv3 + identity / downsample) in one launch (k_bottleneck_f16x2)
+
+
+def bottleneck_ok(x: torch.Tensor, pk1: dict, pk2: dict, pk3: dict, pkd: Optional[dict]) -> bool:
+    """Shapes csrc/bottleneck_kernels.hip takes: fp16-pair arithmetic, a 64-channel 3x3 stride-1 middle convolution between two 1x1 layers, frozen
+    BatchNorm on all of them, identity residual (Cin == Cout) or a stride-1 1x1 downsample of a 64-channel input."""
+    def one(pk):
+        return pk["ndim"] == 2 and tuple(pk["kernel"]) == (1, 1) and tuple(pk["strides"]) == (1, 1) and not pk["transposed"] and pk["scale"] is not None
+    if not (FUSE_BOTTLENECKS and ARITHMETIC == "f16x2" and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        return False
+    if not (one(pk1) and one(pk3) and pk2["ndim"] == 2 and tuple(pk2["kernel"]) == (3, 3) and tuple(pk2["strides"]) == (1, 1) and tuple(pk2["pads"]) == (1, 1)
+            and pk2["scale"] is not None and pk1["cout"] == 64 and pk2["cin"] == 64 and pk2["cout"] == 64 and pk3["cin"] == 64 and pk3["cout"] % 32 == 0
+            and pk1["cin"] % 32 == 0 and pk1["cin"] == x.shape[3]):
+        return False
+    if pkd is not None:
+        if not (one(pkd) and pkd["cin"] == 64 and pk1["cin"] == 64 and pkd["cout"] == pk3["cout"]):
+            return False
+    elif pk1["cin"] != pk3["cout"]:
+        return False
+    return x.numel() // x.shape[3] * max(pk1["cin"], pk3["cout"]) * 4 < 0xfffffff0
+
+
+def conv2d_bottleneck_nhwc(x: torch.Tensor, pk1: dict, pk2: dict, pk3: dict, pkd: Optional[dict] = None) -> torch.Tensor:
+    """relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + identity) of a stage-1 ResNet bottleneck in ONE launch (csrc/bottleneck_kernels.hip);
+    identity = x, or bnD(convD(x)) with ``pkd``.  x (N,H,W,Cin) contiguous fp32 -> (N,H,W,pk3 cout)."""
+    assert bottleneck_ok(x, pk1, pk2, pk3, pkd)
+    n, h, w, cin = x.shape
+    cout = pk3["cout"]
+    out = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    (p1, i1), (p2, i2), (p3, i3) = split_planes_f16(pk1), split_planes_f16(pk2), split_planes_f16(pk3)
+    pd, idd = split_planes_f16(pkd) if pkd is not None else (None, 1.0)
+    in_amax = amax_of(x)
+    out_amax = None if NO_AMAX_COMMIT else AMAX.take(x.device)
+    gw = guard_word(x.device)
+    gl = (ctypes.c_float * 4)(*([guard_l1(pk1), guard_l1(pk2), guard_l1(pk3), guard_l1(pkd) if pkd is not None else 0.0] if gw is not None else [0.0] * 4))
+    m = n * h * w
+    flops = 2 * m * 64 * (cin + 9 * 64 + cout) + (2 * m * cin * cout if pkd is not None else 0)
+    nbytes = 4 * (x.numel() + out.numel() + sum(pk["w"].numel() for pk in (pk1, pk2, pk3) + ((pkd,) if pkd is not None else ())))
+    name = "k_bottleneck/f16x2"
+    thunk = lambda: check(lib.ndet_bottleneck_f16x2(_ptr(x), n, h, w, cin, cout, _ptr(p1), i1, _ptr(pk1["scale"]), _ptr(pk1["shift"]), _ptr(p2), i2,
+                                                    _ptr(pk2["scale"]), _ptr(pk2["shift"]), _ptr(p3), i3, _ptr(pk3["scale"]), _ptr(pk3["shift"]), _ptr(pd), idd,
+                                                    _ptr(None if pkd is None else pkd["scale"]), _ptr(None if pkd is None else pkd["shift"]), _ptr(in_amax),
+                                                    _ptr(out_amax), _ptr(out), gl, GUARD_TOL, _ptr(gw), st), "bottleneck_f16x2")
+    if launch_hook is not None:
+        launch_hook(flops, thunk, name)
+    else:
+        trace.span(name, thunk, flops=flops, bytes=nbytes, kind="conv")
+    if out_amax is not None:
+        _tag_amax(out, out_amax)
+    return out
+
+
 def bn_relu_maxpool_nhwc(x: torch.Tensor, bn: nn.BatchNorm2d) -> torch.Tensor:
     """x (N,H,W,C) contiguous -> MaxPool2d(3,2,1)(relu(bn_eval(x))) in one pass (ResNet stem tail)."""
     assert x.is_cuda and x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32

@@ -1,5 +1,6 @@
 """GPU parity of the hand-written fp32-MFMA Conv3d (csrc/conv3d_kernels.hip) against plain PyTorch fp32 references:
 F.conv3d / F.conv_transpose3d / F.batch_norm evaluated on the CPU (the oracle's ops), and the library modules."""
+import copy
 import pytest
 import torch
 import torch.nn.functional as F
@@ -554,3 +555,49 @@ def test_upsampled_residual_rows_on_every_tile(device, arith, grid):
         finally:
             conv3d.set_arithmetic(prev)
             conv3d.DIRECT_EPILOGUE = True
+
+
+@pytest.mark.parametrize("inplanes,nhw", [(256, (3, 13, 37)), (64, (3, 13, 37)), (256, (2, 60, 80)), (64, (2, 60, 80)), (256, (1, 4, 16)), (64, (5, 3, 5))])
+def test_whole_bottleneck_in_one_launch(device, inplanes, nhw):
+    """csrc/bottleneck_kernels.hip: conv1 -> bn1 -> ReLU -> conv2 -> bn2 -> ReLU -> conv3 -> bn3 -> (+ identity | + bnD(convD x)) -> ReLU of a stage-1
+    ResNet bottleneck (mmdet Bottleneck.forward, style 'pytorch', behind nerfdet.py:140) in ONE launch, on 4 x 16 pixel patches with conv1 evaluated
+    on the patch's halo.  Against the module in fp64 on the CPU: rms error <= 1.15 x the two-launch path's (conv1, then conv2 -> conv3 chained) and
+    < 1e-6 of the output's rms; elementwise <= 2e-5 x the output scale.  NOT bit-identical to the two launches, by construction: there conv1's
+    output is scaled by the whole tensor's maximum, here by the patch's own (a finer scale -- the whole tensor's maximum does not exist before
+    every patch has been evaluated).  Map sizes that are no multiples of the patch (ragged right / bottom edges, maps smaller than one patch)."""
+    from nerfdet_amd import conv3d as C
+    from nerfdet_amd.backbone import Bottleneck
+    torch.manual_seed(inplanes + nhw[1])
+    ds = None
+    if inplanes != 256:
+        ds = nn.Sequential(nn.Conv2d(inplanes, 256, 1, 1, bias=False), nn.BatchNorm2d(256))
+    blk = Bottleneck(inplanes, 64, 1, ds).eval()
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+        x = torch.relu(torch.randn(*nhw, inplanes)) * torch.exp(0.5 * torch.randn(*nhw, 1))
+        ref = copy.deepcopy(blk).double()(x.permute(0, 3, 1, 2).double()).permute(0, 2, 3, 1)
+        blk.to(device)
+        prev = C.set_arithmetic("f16x2")
+        try:
+            xd = x.to(device)
+            C.guard_begin(device)
+            assert C.bottleneck_ok(xd, C.packed([blk.conv1], blk.bn1), C.packed([blk.conv2], blk.bn2), C.packed([blk.conv3], blk.bn3),
+                                   None if ds is None else C.packed([ds[0]], ds[1]))
+            fused = blk.forward_nhwc(xd)
+            assert C.amax_value(fused._ndet_amax) == float(fused.abs().max()), "the epilogue's max |out| is not the tensor's"
+            C.FUSE_BOTTLENECKS = False
+            try:
+                two = blk.forward_nhwc(x.to(device))
+            finally:
+                C.FUSE_BOTTLENECKS = True
+            assert not C.guard_tripped(device)
+        finally:
+            C.set_arithmetic(prev)
+    rms = lambda a: ((a.cpu().double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    e_fused, e_two = rms(fused), rms(two)
+    scale = max(1.0, float(ref.abs().max()))
+    assert fused.shape == ref.shape
+    assert float((fused.cpu().double() - ref).abs().max()) <= 2e-5 * scale
+    assert e_fused < 1e-6 and e_fused <= 1.15 * e_two, (e_fused, e_two)
