@@ -18,6 +18,10 @@
 //      computed by a fourth GEMM on the patch's own x rows kept in LDS from phase A (WD: 64 -> 256).
 //
 // The price: conv1 is evaluated on 128 rows per 64 output pixels (2x; the patch is small so that two workgroups fit a CU: 62 KB of LDS).
+// The kernel is a chain of L2 / HBM round trips (8 chunks of x, 9 taps of W2, W3 slices, identity rows: ~1 us each against 0.2 us of MFMA work per
+// step -- s_memtime stamps of the first form: 31 us per workgroup, 5x its matrix time), so every phase keeps the next THREE steps' loads in flight
+// in statically indexed register rings (static_for: the indices are template constants, nothing the optimiser has to prove), and phase E's weight
+// fragments and identity rows are requested before phase D starts.
 // fp16-pair arithmetic only (the six-product bf16x3 mode keeps the two-launch path): three v_mfma_f32_32x32x16_f16 products per multiply.
 #include "spl_common.hpp"
 
@@ -47,11 +51,30 @@ struct BottleneckParams {
     int nt;                 // non-temporal stores for the output
 };
 
-template <bool DS>
+#include <type_traits>
+template <int I> using ic = std::integral_constant<int, I>;
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(ic<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+#ifdef BT_STAMPS      // diagnostic builds (tools/diag/bottleneck_stamps.py): thread 0 of every workgroup records the 100 MHz clock at the phase boundaries
+__device__ unsigned long long* g_bt_stamps = nullptr;
+#define STAMP(i) do { if (g_bt_stamps && tid == 0) g_bt_stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+extern "C" int ndet_bt_set_stamps(unsigned long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_bt_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -3; }
+#else
+#define STAMP(i)
+#endif
+
+template <bool DS, int NCH>
 __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckParams p) {
     constexpr int APL = BT_AROWS * SPL_RS, BPL = BT_MID * SPL_RS;      // staging planes, rows padded to 40 elements
     constexpr int STAGE = 2 * (APL + BPL);
     constexpr int Y1PL = BT_AROWS * BT_MID, Y2PL = BT_OROWS * BT_MID;
+    constexpr int NCB = 2;                     // 32-column slices of the output per wave: Cout = 4 waves x NCB x 32 = 256
     extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
     uint16_t* As = lds16;                      // [2][128][40]
     uint16_t* Bs = lds16 + 2 * APL;            // [2][64][40]
@@ -76,6 +99,7 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         rowok[tid] = (tid < BT_HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? 1 : 0;
     }
+    STAMP(0);
 
     // ---------------- phase A: conv1 (1x1, Cin -> 64) on the 128 halo rows ----------------
     const int wm = wave >> 1, wn = wave & 1;         // 2 x 2 waves: 64 rows x 32 channels each
@@ -99,23 +123,27 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
             rowptr[i] = p.x + (((int64_t)n * p.H + (aok[i] ? iy : 0)) * p.W + (aok[i] ? ix : 0)) * p.Cin + akq * 4;
             own[i] = (hr < BT_HROWS && hy >= 1 && hy <= BT_TH && hx >= 1 && hx <= BT_TW) ? (hy - 1) * BT_TW + (hx - 1) : -1;
         }
-        const int nch = p.Cin / CBK;
-        float4 ra[4];
-        uint4 rb0, rb1;
-        auto load_tile = [&](int ch) {
+        const uint16_t* w1p = p.w1 + (int64_t)brow_ * CBK + bkg * 8;
+        constexpr int RING = NCH < 4 ? NCH : 4;           // chunk c lives in register set c % RING; RING - 1 chunks travel while one multiplies
+        typedef unsigned bt_u32x4 __attribute__((ext_vector_type(4)));
+        f32x4_ ra[RING][4];                               // (native vector types: arrays of HIP's struct-wrapped uint4 are left on the stack -- every
+        bt_u32x4 rb[RING][2];                             //  access a scratch round trip behind a vmcnt(0) that drains the whole ring)
+        auto load_tile = [&](auto S, int ch) {
+            constexpr int s = decltype(S)::value;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float4 v = *reinterpret_cast<const float4*>(rowptr[i] + ch * CBK);     // always issued (a legal address): no divergence
-                ra[i] = aok[i] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                const f32x4_ v = *reinterpret_cast<const f32x4_*>(rowptr[i] + ch * CBK);     // always issued (a legal address): no divergence
+                ra[s][i] = aok[i] ? v : (f32x4_){0.f, 0.f, 0.f, 0.f};
             }
-            rb0 = *reinterpret_cast<const uint4*>(p.w1 + (((int64_t)ch * 2 + 0) * BT_MID + brow_) * CBK + bkg * 8);
-            rb1 = *reinterpret_cast<const uint4*>(p.w1 + (((int64_t)ch * 2 + 1) * BT_MID + brow_) * CBK + bkg * 8);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) rb[s][pl] = *reinterpret_cast<const bt_u32x4*>(w1p + ((int64_t)ch * 2 + pl) * BT_MID * CBK);
         };
-        auto store_tile = [&](int ch) {
+        auto store_tile = [&](auto S, int ch) {
+            constexpr int s = decltype(S)::value;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 uint2 s0, s1, s2;
-                spl_split<1>(ra[i], xs, s0, s1, s2);
+                spl_split<1>(make_float4(ra[s][i].x, ra[s][i].y, ra[s][i].z, ra[s][i].w), xs, s0, s1, s2);
                 uint16_t* dst = As + (arow_ + 32 * i) * SPL_RS + akq * 4;
                 *reinterpret_cast<uint2*>(dst) = s0;
                 *reinterpret_cast<uint2*>(dst + APL) = s1;
@@ -126,17 +154,17 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
                 }
             }
             uint16_t* dst = Bs + brow_ * SPL_RS + bkg * 8;
-            *reinterpret_cast<uint4*>(dst) = rb0;
-            *reinterpret_cast<uint4*>(dst + BPL) = rb1;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<bt_u32x4*>(dst + pl * BPL) = rb[s][pl];
         };
-        load_tile(0);
-        store_tile(0);
+        static_for<0, RING>([&](auto C) { load_tile(C, decltype(C)::value); });
+        store_tile(ic<0>{}, 0);
         __syncthreads();
         const uint16_t* abase = As + (wm * 64 + frow) * SPL_RS + fk;
         const uint16_t* bbase = Bs + (wn * 32 + frow) * SPL_RS + fk;
-        for (int ch = 0; ch < nch; ++ch) {
-            const bool more = ch + 1 < nch;
-            if (more) load_tile(ch + 1);
+        static_for<0, NCH>([&](auto C) {
+            constexpr int ch = decltype(C)::value;
+            if constexpr (ch + RING < NCH) load_tile(ic<ch % RING>{}, ch + RING);       // into the set chunk ch just left
 #pragma unroll
             for (int ks = 0; ks < CBK / 16; ++ks) {
                 bf16x8 fa[2][2], fb[2];
@@ -155,10 +183,26 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
                 for (int a = 0; a < 2; ++a) acc1[a] = spl_mfma32<1>(fa[0][a], fb[0], acc1[a]);
             }
             __syncthreads();
-            if (more) store_tile(ch + 1);
+            if constexpr (ch + 1 < NCH) store_tile(ic<(ch + 1) % RING>{}, ch + 1);
             __syncthreads();
-        }
+        });
     }
+    STAMP(1);
+
+    // conv2's weight fragments (one output channel per lane, 4 K slices x 2 planes per tap) stream from L2 three taps ahead: a ring of four sets.
+    // The first three are requested here, before phase B: they land while the halo image is written.
+    const int wm2 = wave >> 1, wn2 = wave & 1;       // phase C: 32 output pixels x 32 channels per wave
+    bf16x8 fw[4][4][2];                               // [ring set][k slice][plane]
+    const uint16_t* w2p = p.w2 + (int64_t)(wn2 * 32 + frow) * CBK + fk;
+    auto load_w2 = [&](auto S, int tap) {
+        constexpr int s = decltype(S)::value;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                fw[s][ks][pl] = *reinterpret_cast<const bf16x8*>(w2p + ((((int64_t)tap * 2 + (ks >> 1)) * 2 + pl) * BT_MID) * CBK + (ks & 1) * 16);
+    };
+    static_for<0, 3>([&](auto T) { load_w2(T, decltype(T)::value); });
 
     // workgroup maximum of a wave-level value (uniform result; a barrier inside)
     auto wg_maximum = [&](float v) -> float {
@@ -205,9 +249,9 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
             }
     }
     __syncthreads();
+    STAMP(2);
 
-    // ---------------- phase C: conv2 (3x3, 64 -> 64) out of the halo image; W2 fragments from L2, one tap ahead ----------------
-    const int wm2 = wave >> 1, wn2 = wave & 1;       // 32 output pixels x 32 channels per wave
+    // ---------------- phase C: conv2 (3x3, 64 -> 64) out of the halo image ----------------
     f32x16 acc2[2];                                   // two accumulators taken in turn: no MFMA waits for the one before it
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -215,20 +259,10 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
         for (int r = 0; r < 16; ++r) acc2[a][r] = 0.f;
     {
         const int po = wm2 * 32 + frow, py = po >> 4, px = po & 15;
-        const int co = wn2 * 32 + frow;
-        bf16x8 fw[2][4][2];                           // [buffer][k slice][plane]
-        auto load_w2 = [&](int buf, int tap) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-                    fw[buf][ks][pl] = *reinterpret_cast<const bf16x8*>(p.w2 + ((((int64_t)tap * 2 + (ks >> 1)) * 2 + pl) * BT_MID + co) * CBK + (ks & 1) * 16 + fk);
-        };
-        load_w2(0, 0);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap + 1 < 9) load_w2((tap + 1) & 1, tap + 1);
-            const int dy = tap / 3, dx = tap % 3;
+        static_for<0, 9>([&](auto T) {
+            constexpr int tap = decltype(T)::value;
+            if constexpr (tap + 3 < 9) load_w2(ic<(tap + 3) % 4>{}, tap + 3);
+            constexpr int dy = tap / 3, dx = tap % 3;
             const int irow = (py + dy) * BT_HW + px + dx;
             const uint16_t* ya = Y1 + irow * BT_MID;
 #pragma unroll
@@ -237,12 +271,54 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) fa[pl] = *reinterpret_cast<const bf16x8*>(ya + pl * Y1PL + (((2 * ks + fh) ^ (irow & 7)) << 3));
                 f32x16& cc = acc2[ks & 1];
-                cc = spl_mfma32<1>(fa[0], fw[tap & 1][ks][1], cc);
-                cc = spl_mfma32<1>(fa[1], fw[tap & 1][ks][0], cc);
-                cc = spl_mfma32<1>(fa[0], fw[tap & 1][ks][0], cc);
+                cc = spl_mfma32<1>(fa[0], fw[tap % 4][ks][1], cc);
+                cc = spl_mfma32<1>(fa[1], fw[tap % 4][ks][0], cc);
+                cc = spl_mfma32<1>(fa[0], fw[tap % 4][ks][0], cc);
             }
-        }
+        });
     }
+    STAMP(3);
+
+    // phase E's operands, requested now: the W3 (and WD) fragments of both column slices of this wave and the identity rows of the first one
+    // travel while BN2 + ReLU + the split of phase D run.
+    const unsigned obytes = (unsigned)((int64_t)p.N * p.H * p.W * p.Cout * 4);
+    const unsigned xbytes = (unsigned)((int64_t)p.N * p.H * p.W * p.Cin * 4);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, obytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, xbytes, 0x00020000);
+    bf16x8 f3[NCB][4][2];
+    auto load_frags = [&](auto CB, const uint16_t* wp) {
+        constexpr int c = decltype(CB)::value;
+        const int co = wave * 32 + c * 128 + frow;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                f3[c][ks][pl] = *reinterpret_cast<const bf16x8*>(wp + (((int64_t)(ks >> 1) * 2 + pl) * p.Cout + co) * CBK + (ks & 1) * 16 + fk);
+    };
+    static_for<0, NCB>([&](auto CB) { load_frags(CB, p.w3); });
+    // byte offset of (row tile rt, register r) of this lane's column in slice 0: pixel (y0 + py, x0 + px), channel wave * 32 + frow
+    unsigned off[2][16];
+    {
+        const unsigned vo = (unsigned)(((((int64_t)n * p.H + y0) * p.W + x0 + 4 * fh) * p.Cout + wave * 32 + frow) * 4);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = (r & 3) + 8 * (r >> 2);             // row inside the 32-row tile, without the lane's 4 fh
+                const int py = rt * 2 + (q >> 4), px = (q & 15) + 4 * fh;
+                const bool ok = y0 + py < p.H && x0 + px < p.W;
+                off[rt][r] = ok ? vo + (unsigned)((py * p.W + (q & 15)) * p.Cout * 4) : 0xfffffff0u;      // outside the descriptor: reads 0, stores dropped
+            }
+    }
+    float rr[2][16];                                  // identity rows of the slice about to be finished (Cin == Cout: the same byte offsets in x)
+    auto load_identity = [&](int cb) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                rr[rt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rres, off[rt][r] == 0xfffffff0u ? 0xfffffff0u : off[rt][r] + (unsigned)(cb * 128 * 4), 0, 0));
+    };
+    if (!DS) load_identity(0);
 
     // ---------------- phase D: BN2 + ReLU, into LDS as the A operand of conv3 ----------------
     float ymax2;
@@ -257,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
             acc2[0][r] = v;
             m = fmaxf(m, v);
         }
-        ymax2 = wg_maximum(m);           // (its barriers: every wave is done with the halo image's staging neighbour, the planes Y2 overwrites)
+        ymax2 = wg_maximum(m);           // (its barriers: every wave has left phase A's staging planes, which Y2 overwrites)
         const float ys2 = conv_xscale_of(ymax2);
         if (p.guard && tid == 0 && ymax2 * p.g3 * 0x1p-39f > p.gtol) atomicOr(p.guard, 1u);
 #pragma unroll
@@ -272,80 +348,68 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
         }
     }
     __syncthreads();
+    STAMP(4);
 
-    // ---------------- phase E: conv3 (1x1, 64 -> Cout) + BN3 + identity + ReLU, 32-column slices per wave ----------------
+    // ---------------- phase E: conv3 (1x1, 64 -> 256) + BN3 + identity + ReLU, two 32-column slices per wave ----------------
     float omax = 0.0f;
     {
         const float osc3 = conv_xinv_of(ymax2) * p.w3inv;
         const float oscd = DS ? conv_xinv_of(amax_in) * p.wdinv : 0.0f;
-        const unsigned obytes = (unsigned)((int64_t)p.N * p.H * p.W * p.Cout * 4);
-        const unsigned xbytes = (unsigned)((int64_t)p.N * p.H * p.W * p.Cin * 4);
-        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, obytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, xbytes, 0x00020000);
-        for (int cb = wave * 32; cb < p.Cout; cb += 4 * 32) {
-            const int co = cb + frow;
-            const float sc3 = p.s3[co], sh3 = p.b3[co];
-            const float scd = DS ? p.sd[co] : 0.0f, shd = DS ? p.bd[co] : 0.0f;
-            // one set of fragment registers: W3's for the main product, then (first block of the stage) WD's for the identity branch
-            bf16x8 fw[4][2];
-            auto load_frags = [&](const uint16_t* wp) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl)
-                        fw[ks][pl] = *reinterpret_cast<const bf16x8*>(wp + (((int64_t)(ks >> 1) * 2 + pl) * p.Cout + co) * CBK + (ks & 1) * 16 + fk);
-            };
-            auto gemm = [&](f32x16 (&cc)[2], const uint16_t* img) {
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) cc[rt][r] = 0.f;
-                    const int arow = rt * 32 + frow;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        bf16x8 fa[2];
-#pragma unroll
-                        for (int pl = 0; pl < 2; ++pl) fa[pl] = *reinterpret_cast<const bf16x8*>(img + pl * Y2PL + arow * BT_MID + (((2 * ks + fh) ^ (arow & 7)) << 3));
-                        cc[rt] = spl_mfma32<1>(fa[0], fw[ks][1], cc[rt]);
-                        cc[rt] = spl_mfma32<1>(fa[1], fw[ks][0], cc[rt]);
-                        cc[rt] = spl_mfma32<1>(fa[0], fw[ks][0], cc[rt]);
-                    }
-                }
-            };
-            f32x16 c2[2], cd[2];
-            load_frags(p.w3);
-            gemm(c2, Y2);
-            if (DS) {
-                load_frags(p.wd);
-                gemm(cd, XO);
-            }
-            // lane part of the output address: pixel (y0, x0 + 4 fh), channel co; a register's row adds (row tile, r) -> (py, px) uniformly
-            const unsigned vo = (unsigned)(((((int64_t)n * p.H + y0) * p.W + x0 + 4 * fh) * p.Cout + co) * 4);
+        auto gemm = [&](auto CB, f32x16 (&cc)[2], const uint16_t* img) {
+            constexpr int c = decltype(CB)::value;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                unsigned off[16];
-                float rr[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int q = (r & 3) + 8 * (r >> 2);             // row inside the 32-row tile, without the lane's 4 fh
-                    const int py = rt * 2 + (q >> 4), px = (q & 15) + 4 * fh;
-                    const bool ok = y0 + py < p.H && x0 + px < p.W;
-                    off[r] = ok ? vo + (unsigned)((py * p.W + (q & 15)) * p.Cout * 4) : 0xfffffff0u;      // outside the descriptor: reads 0, stores dropped
-                    rr[r] = DS ? (cd[rt][r] * oscd) * scd + shd : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rres, off[r], 0, 0));    // identity: Cin == Cout
-                }
+                for (int r = 0; r < 16; ++r) cc[rt][r] = 0.f;
+                const int arow = rt * 32 + frow;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = (c2[rt][r] * osc3) * sc3 + sh3;
-                    v += rr[r];
-                    v = fmaxf(v, 0.f);
-                    if (p.nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, off[r], 0, 2);
-                    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, off[r], 0, 0);
-                    if (off[r] != 0xfffffff0u) omax = fmaxf(omax, fabsf(v));
+                for (int ks = 0; ks < 4; ++ks) {
+                    bf16x8 fa[2];
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) fa[pl] = *reinterpret_cast<const bf16x8*>(img + pl * Y2PL + arow * BT_MID + (((2 * ks + fh) ^ (arow & 7)) << 3));
+                    cc[rt] = spl_mfma32<1>(fa[0], f3[c][ks][1], cc[rt]);
+                    cc[rt] = spl_mfma32<1>(fa[1], f3[c][ks][0], cc[rt]);
+                    cc[rt] = spl_mfma32<1>(fa[0], f3[c][ks][0], cc[rt]);
                 }
             }
-        }
+        };
+        f32x16 c2[NCB][2];
+        static_for<0, NCB>([&](auto CB) { gemm(CB, c2[decltype(CB)::value], Y2); });
+        if (DS) static_for<0, NCB>([&](auto CB) { load_frags(CB, p.wd); });      // the identity branch of the stage's first block: WD's fragments in W3's place
+        static_for<0, NCB>([&](auto CB) {
+            constexpr int c = decltype(CB)::value;
+            const int co = wave * 32 + c * 128 + frow;
+            const float sc3 = p.s3[co], sh3 = p.b3[co];
+            if (DS) {
+                const float scd = p.sd[co], shd = p.bd[co];
+                f32x16 cd[2];
+                gemm(CB, cd, XO);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rr[rt][r] = (cd[rt][r] * oscd) * scd + shd;
+            }
+            float vv[2][16];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vv[rt][r] = fmaxf(((c2[c][rt][r] * osc3) * sc3 + sh3) + rr[rt][r], 0.f);
+            if constexpr (c + 1 < NCB) { if (!DS) load_identity(c + 1); }      // (rr is consumed: the next slice's identity rows travel under these stores)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = off[rt][r] != 0xfffffff0u;
+                    const unsigned o = ok ? off[rt][r] + (unsigned)(c * 128 * 4) : 0xfffffff0u;
+                    if (p.nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv[rt][r]), rout, o, 0, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv[rt][r]), rout, o, 0, 0);
+                    if (ok) omax = fmaxf(omax, fabsf(vv[rt][r]));
+                }
+        });
     }
+    STAMP(5);
     if (p.amax_out) conv_amax_commit(p.amax_out, omax);
+    STAMP(6);
 }
 
 extern "C" int ndet_bottleneck_f16x2(const float* x, int N, int H, int W, int Cin, int Cout, const uint16_t* w1_planes, float w1_inv_scale, const float* scale1,
@@ -357,7 +421,7 @@ extern "C" int ndet_bottleneck_f16x2(const float* x, int N, int H, int W, int Ci
     NDET_REQUIRE(x && out && w1_planes && w2_planes && w3_planes && scale1 && shift1 && scale2 && shift2 && scale3 && shift3 && in_amax, NDET_E_INVALID,
                  "%s: null pointer", fn);
     NDET_REQUIRE(N > 0 && H > 0 && W > 0, NDET_E_INVALID, "%s: sizes must be positive", fn);
-    NDET_REQUIRE(Cin % CBK == 0 && Cout % 32 == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d, Cout=%d of 32", fn, Cin, CBK, Cout);
+    NDET_REQUIRE((Cin == 64 || Cin == 256) && Cout == 256, NDET_E_UNSUPPORTED, "%s: built for Cin = 64 or 256 and Cout = 256 (got %d, %d)", fn, Cin, Cout);
     NDET_REQUIRE(w1_inv_scale > 0.0f && w2_inv_scale > 0.0f && w3_inv_scale > 0.0f, NDET_E_INVALID, "%s: the weight planes' inverse scales must be positive", fn);
     const bool ds = wd_planes != nullptr;
     if (ds) {
@@ -384,16 +448,19 @@ extern "C" int ndet_bottleneck_f16x2(const float* x, int N, int H, int W, int Ci
     const int64_t blocks = (int64_t)N * p.tiles_x * p.tiles_y;
     NDET_REQUIRE(blocks < ((int64_t)1 << 31), NDET_E_UNSUPPORTED, "%s: too many patches", fn);
     const size_t lds = (size_t)(2 * (BT_AROWS + BT_MID) * SPL_RS + 2 * BT_AROWS * BT_MID + (ds ? 2 * BT_OROWS * BT_MID : 0)) * sizeof(uint16_t);
-    static int attr_state[16][2] = {{0}};
+    const void* kfn = ds ? (const void*)k_bottleneck_f16x2<true, 2> : (Cin == 64 ? (const void*)k_bottleneck_f16x2<false, 2> : (const void*)k_bottleneck_f16x2<false, 8>);
+    const int variant = ds ? 0 : (Cin == 64 ? 1 : 2);
+    static int attr_state[16][3] = {{0}};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (lds > 64 * 1024 && attr_state[dev][ds] == 0) {
-        hipError_t e = hipFuncSetAttribute(ds ? (const void*)k_bottleneck_f16x2<true> : (const void*)k_bottleneck_f16x2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024 && attr_state[dev][variant] == 0) {
+        hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit to %zu bytes: %s", fn, lds, hipGetErrorString(e));
-        attr_state[dev][ds] = 1;
+        attr_state[dev][variant] = 1;
     }
-    if (ds) hipLaunchKernelGGL(k_bottleneck_f16x2<true>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(k_bottleneck_f16x2<false>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    if (ds) hipLaunchKernelGGL((k_bottleneck_f16x2<true, 2>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    else if (Cin == 64) hipLaunchKernelGGL((k_bottleneck_f16x2<false, 2>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_bottleneck_f16x2<false, 8>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
