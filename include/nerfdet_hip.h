@@ -404,9 +404,10 @@ int ndet_bn_relu_maxpool_nhwc(const float* x, const float* scale, const float* s
  * Arithmetic of ndet_conv_ndhwc_split (fp32 operands as exact sums of three bf16 terms, six MFMA products). */
 int ndet_stem_pack_weights(const float* w_64x3x7x7, uint16_t* planes /* (3, 64, 176) */, void* stream);
 
-/* The launch itself (see above; conv1 / bn1 / relu / maxpool behind mmdet3d/models/detectors/nerfdet.py:140). */
+/* The launch itself (see above; conv1 / bn1 / relu / maxpool behind mmdet3d/models/detectors/nerfdet.py:140).  out_amax (may be null): max |out|
+ * into a zeroed amax slot -- the first bottleneck's fp16-pair scale without another pass over the 61 MB. */
 int ndet_stem_conv_bn_relu_maxpool(const float* images, int N, int H, int W, int64_t stride_n, int64_t stride_c, int64_t stride_y,
-                                   int64_t stride_x, const uint16_t* w_planes, const float* scale, const float* shift, float* out,
+                                   int64_t stride_x, const uint16_t* w_planes, const float* scale, const float* shift, float* out, float* out_amax,
                                    void* stream);
 
 /* ---- input contract: what the data pipeline hands to nerfdet.forward_*, from decoded,

@@ -711,9 +711,12 @@ def stem_conv_bn_relu_maxpool(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm
     ch, cw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     out = torch.empty((n, (ch - 1) // 2 + 1, (cw - 1) // 2 + 1, 64), dtype=torch.float32, device=x.device)
     sn, sc, sy, sx = x.stride()
+    out_amax = AMAX.take(x.device) if (ARITHMETIC == "f16x2" and not NO_AMAX_COMMIT) else None       # the first bottleneck's activation scale
     trace.span("k_stem_conv_pool", lambda: check(lib.ndet_stem_conv_bn_relu_maxpool(_ptr(x), n, h, w, sn, sc, sy, sx, _ptr(hit[1]), _ptr(scale), _ptr(shift),
-                                                                                  _ptr(out), st), "stem_conv_bn_relu_maxpool"),
+                                                                                  _ptr(out), _ptr(out_amax), st), "stem_conv_bn_relu_maxpool"),
                flops=2 * n * ch * cw * 64 * 147, bytes=4 * (x.numel() + out.numel()), kind="stem")
+    if out_amax is not None:
+        _tag_amax(out, out_amax)
     return out
 
 

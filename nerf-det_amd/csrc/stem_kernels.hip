@@ -9,7 +9,7 @@
 // 8 consecutive k of one convolution pixel -- is then 8 consecutive input pixels of one patch row, four 4-byte LDS reads.  The weight
 // fragments (64 x 176 x 3 planes, 68 KB) live in the waves' registers for the whole launch.  BN + ReLU are applied to the accumulators,
 // the 7 x 17 x 64 tile goes through LDS, and the 3 x 8 pooled pixels leave as whole 256-byte channel rows (channels-last output).
-#include "ndet_common.hpp"
+#include "conv_common.hpp"      // conv_amax_commit: max |out| for the fp16-pair layer that follows
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -41,6 +41,7 @@ struct StemParams {
     const float* scale;    // (64)
     const float* shift;
     float* out;            // (N, PH, PW, 64)
+    float* amax_out;       // max |out| slot (conv_common.hpp) or null
 };
 
 __device__ __forceinline__ uint32_t st_pack(float x, float y) {
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_conv_pool(const StemParams p) {
             ra[i] = ok ? base[c * p.sc + y * p.sy + x * p.sx] : 0.0f;
         }
     };
+    float omax = 0.0f;
     __syncthreads();
     int t = blockIdx.x;
     if (t < p.tiles) load_patch(t);
@@ -170,11 +172,13 @@ __global__ __launch_bounds__(256, 2) void k_stem_conv_pool(const StemParams p) {
                         }
                     }
                 *reinterpret_cast<float4*>(p.out + (((int64_t)n * p.PH + py) * p.PW + px) * 64 + q * 4) = m;
+                omax = fmaxf(fmaxf(omax, fmaxf(m.x, m.y)), fmaxf(m.z, m.w));       // (post-ReLU: non-negative)
             }
         }
         // the next iteration's patch stores touch P only; its barrier (A) orders them against this tile's MFMA reads (all waves passed (B))
         // and orders the next Cs writes against this pooling
     }
+    if (p.amax_out) conv_amax_commit(p.amax_out, omax);                  // once per persistent workgroup
 }
 
 // stem weight (64, 3, 7, 7) fp32 -> (3 planes, 64, 176) bf16 with k = (ky * 3 + c) * 8 + kx; kx = 7 and k >= 168 are zero
@@ -205,7 +209,7 @@ extern "C" int ndet_stem_pack_weights(const float* w_64x3x7x7, uint16_t* planes,
 
 extern "C" int ndet_stem_conv_bn_relu_maxpool(const float* images, int N, int H, int W, int64_t stride_n, int64_t stride_c, int64_t stride_y,
                                               int64_t stride_x, const uint16_t* w_planes, const float* scale, const float* shift, float* out,
-                                              void* stream) {
+                                              float* out_amax, void* stream) {
     const char* fn = "ndet_stem_conv_bn_relu_maxpool";
     NDET_REQUIRE(images && w_planes && scale && shift && out, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(N > 0 && H >= 7 && W >= 7, NDET_E_INVALID, "%s: bad sizes", fn);
@@ -219,7 +223,7 @@ extern "C" int ndet_stem_conv_bn_relu_maxpool(const float* images, int N, int H,
     const int64_t tiles = (int64_t)N * p.tiles_y * p.tiles_x;
     NDET_REQUIRE(tiles < ((int64_t)1 << 31), NDET_E_UNSUPPORTED, "%s: too many tiles", fn);
     p.tiles = (int)tiles;
-    p.w = w_planes; p.scale = scale; p.shift = shift; p.out = out;
+    p.w = w_planes; p.scale = scale; p.shift = shift; p.out = out; p.amax_out = out_amax;
     const int grid = (int)(tiles < 512 ? tiles : 512);               // two persistent workgroups per CU
     hipLaunchKernelGGL(k_stem_conv_pool, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     NDET_CHECK_LAUNCH(fn);
