@@ -28,6 +28,32 @@ def _dense_nhwc(t):
     return f if rows.is_contiguous() else rows.contiguous().permute(0, 3, 1, 2)
 
 
+# ---- deterministic gradient scatter (tests) ----
+# The backward kernels scatter with float atomics: the order of the adds, and with it the last bits of every gradient, changes from run to run
+# (Adam's sign-like first steps amplify that into visibly different training trajectories: DESIGN.md, training).  ``set_deterministic(True)`` switches
+# them to 64-bit fixed-point integer atomics (csrc/ndet_common.hpp::ndet_scatter_add: contributions rounded to multiples of 2^-40, integer sums are
+# order-independent): bitwise reproducible gradients, ~2x the scatter time and twice the buffer.  The default stays the fast float path.
+DETERMINISTIC = False
+_FIX = 2.0 ** -40
+
+
+def set_deterministic(on: bool) -> bool:
+    """Switch the gradient scatter of K1 / K2 / K4 backward to the order-independent fixed-point form; returns the previous setting."""
+    global DETERMINISTIC
+    prev, DETERMINISTIC = DETERMINISTIC, bool(on)
+    check(_lib.load().ndet_measurement_knob(b"deterministic_scatter", int(DETERMINISTIC)), "measurement_knob")
+    return prev
+
+
+def _grad_buffer(shape, device):
+    """Zeroed accumulation buffer of the scatter: fp32, or int64 fixed point in the deterministic mode (same element indexing)."""
+    return torch.zeros(shape, dtype=torch.int64 if DETERMINISTIC else torch.float32, device=device)
+
+
+def _grad_result(buf):
+    return (buf.double() * _FIX).float() if buf.dtype == torch.int64 else buf
+
+
 class BackprojectMean(torch.autograd.Function):
     """features (n_v,C,h,w) -> (mean (C,X,Y,Z), count (1,X,Y,Z)); nerfdet.py:164-176."""
 
@@ -51,12 +77,12 @@ class BackprojectMean(torch.autograd.Function):
         else:
             g, layout = g_out.contiguous(), NDET_LAYOUT_CN
         g = g.float()
-        dfeat = torch.zeros((n_v, h, w, c), dtype=torch.float32, device=g.device)
+        dfeat = _grad_buffer((n_v, h, w, c), g.device)
         pts = points.float().contiguous()
         pj = projection.float().contiguous()
         check(_lib.load().ndet_backproject_aggregate_bwd(_ptr(g), layout, n_v, c, h, w, dfeat.stride(0), dfeat.stride(1), _ptr(pts), n,
                                                          _ptr(pj), _ptr(dfeat), _stream(g)), "backproject_aggregate_bwd")
-        return dfeat.permute(0, 3, 1, 2), None, None, None
+        return _grad_result(dfeat).permute(0, 3, 1, 2), None, None, None
 
 
 class DensityFeatures(torch.autograd.Function):
@@ -75,13 +101,13 @@ class DensityFeatures(torch.autograd.Function):
         n_v, cm, h, w = m.shape
         n = points[0].numel()
         g = g.float().contiguous()
-        dm = torch.zeros((n_v, h, w, cm), dtype=torch.float32, device=g.device)
+        dm = _grad_buffer((n_v, h, w, cm), g.device)
         assert (m.stride(0), m.stride(2)) == (dm.stride(0), dm.stride(1)), "saved input and gradient buffer must share their pitches"
-        db = torch.zeros((cm,), dtype=torch.float32, device=g.device)
+        db = _grad_buffer((cm,), g.device)
         check(_lib.load().ndet_density_features_bwd(_ptr(g), _ptr(m), n_v, cm, h, w, m.stride(0), m.stride(2), _ptr(bias.float().contiguous()),
                                                     _ptr(points.float().contiguous()), n, _ptr(projection.float().contiguous()), _ptr(dm),
                                                     _ptr(db), _stream(g)), "density_features_bwd")
-        return dm.permute(0, 3, 1, 2), db, None, None, None, None
+        return _grad_result(dm).permute(0, 3, 1, 2), _grad_result(db), None, None, None, None
 
 
 class RayViewStats(torch.autograd.Function):
@@ -104,7 +130,7 @@ class RayViewStats(torch.autograd.Function):
         f, pts, ke = ctx.saved_tensors
         n_v, d, hf, wf = f.shape
         g = g.float().reshape(pts.shape[0], -1).contiguous()
-        df = torch.zeros((n_v, hf, wf, d), dtype=torch.float32, device=g.device)
+        df = _grad_buffer((n_v, hf, wf, d), g.device)
         assert (f.stride(0), f.stride(2)) == (df.stride(0), df.stride(1)), "saved input and gradient buffer must share their pitches"
         from . import rays
         fn = _lib.load().ndet_ray_view_stats_packed_bwd if rays.packed_ok(n_v, d, backward=True) else _lib.load().ndet_ray_view_stats_bwd
@@ -115,7 +141,7 @@ class RayViewStats(torch.autograd.Function):
                    lambda: check(fn(_ptr(g), _ptr(pts), pts.shape[0], _ptr(ke), n_v, ctx.hw[0], ctx.hw[1], _ptr(f), d, hf, wf, f.stride(0), f.stride(2),
                                     _ptr(df), _stream(g)), "ray_view_stats_bwd"),
                    bytes=4 * (g.numel() + n_v * d * hf * wf), atomics_max=pts.shape[0] * n_v * 4 * d, kind="atomics")
-        return df.permute(0, 3, 1, 2), None, None, None
+        return _grad_result(df).permute(0, 3, 1, 2), None, None, None
 
 
 class Composite(torch.autograd.Function):

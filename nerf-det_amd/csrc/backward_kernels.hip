@@ -16,7 +16,7 @@
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void k_backproject_aggregate_bwd(const float* __restrict__ g, int n_views, int C, int h, int w,
                                                                    int64_t view_pitch, int row_pitch, const float* __restrict__ points, int N,
-                                                                   const float* __restrict__ proj, float* __restrict__ dfeat, int n_tiles) {
+                                                                   const float* __restrict__ proj, float* __restrict__ dfeat, int n_tiles, int det) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = ndet_xcd_remap(blockIdx.x, n_tiles);
     for (int j = 0; j < BVOX_PER_TILE / 4; ++j) {
@@ -50,12 +50,12 @@ __global__ __launch_bounds__(256) void k_backproject_aggregate_bwd(const float* 
                 const int b = __builtin_ctzll(m);
                 m &= m - 1ull;
                 const int o = __builtin_amdgcn_readlane(off, b);
-                float* base = dfeat + (int64_t)(r0 + b) * view_pitch + o;
+                const int64_t base = (int64_t)(r0 + b) * view_pitch + o;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (lane + 64 * q < C) unsafeAtomicAdd(base + lane + 64 * q, gv[q]);  // 256 contiguous bytes per instruction
+                    if (lane + 64 * q < C) ndet_scatter_add(dfeat, base + lane + 64 * q, gv[q], det);  // 256 contiguous bytes per instruction
                 for (int c0 = lane + 256; c0 < C; c0 += 64)
-                    unsafeAtomicAdd(base + c0, (LAYOUT == NDET_LAYOUT_NC ? g[(int64_t)n * C + c0] : g[(int64_t)c0 * N + n]) * inv);
+                    ndet_scatter_add(dfeat, base + c0, (LAYOUT == NDET_LAYOUT_NC ? g[(int64_t)n * C + c0] : g[(int64_t)c0 * N + n]) * inv, det);
             }
         }
     }
@@ -72,10 +72,10 @@ extern "C" int ndet_backproject_aggregate_bwd(const float* grad_mean, int grad_l
     const int n_tiles = (N + BVOX_PER_TILE - 1) / BVOX_PER_TILE;
     if (grad_layout == NDET_LAYOUT_NC)
         hipLaunchKernelGGL(k_backproject_aggregate_bwd<NDET_LAYOUT_NC>, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, grad_mean, n_views, C, h, w,
-                           view_pitch, (int)row_pitch, points, N, projection, grad_features_nhwc, n_tiles);
+                           view_pitch, (int)row_pitch, points, N, projection, grad_features_nhwc, n_tiles, g_ndet_deterministic_scatter);
     else
         hipLaunchKernelGGL(k_backproject_aggregate_bwd<NDET_LAYOUT_CN>, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, grad_mean, n_views, C, h, w,
-                           view_pitch, (int)row_pitch, points, N, projection, grad_features_nhwc, n_tiles);
+                           view_pitch, (int)row_pitch, points, N, projection, grad_features_nhwc, n_tiles, g_ndet_deterministic_scatter);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
@@ -90,7 +90,7 @@ extern "C" int ndet_backproject_aggregate_bwd(const float* grad_mean, int grad_l
 __global__ __launch_bounds__(256) void k_density_features_bwd(const float* __restrict__ gout, const float* __restrict__ mapped, int n_views, int cm,
                                                               int h, int w, int64_t mview_pitch, int mrow_pitch, const float* __restrict__ bias,
                                                               const float* __restrict__ points, int N, const float* __restrict__ proj,
-                                                              float* __restrict__ dmapped, float* __restrict__ dbias, int n_tiles) {
+                                                              float* __restrict__ dmapped, float* __restrict__ dbias, int n_tiles, int det) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = ndet_xcd_remap(blockIdx.x, n_tiles);
     const int F = 2 * (3 + cm);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_density_features_bwd(const float* __res
                     const float val = active ? mapped[idx] : 0.0f;
                     if (pass == 0) acc = acc + val;
                     else if (pass == 1) acc = acc + (val - mean) * (val - mean);
-                    else if (active) unsafeAtomicAdd(dmapped + idx, k1 + k2 * (2.0f * (val - mean) - k3));
+                    else if (active) ndet_scatter_add(dmapped, idx, k1 + k2 * (2.0f * (val - mean) - k3), det);
                 }
             }
             const float n_inv = (float)(n_views - c_here);
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_density_features_bwd(const float* __res
             }
         }
     }
-    if (active && dbias_acc != 0.0f) unsafeAtomicAdd(dbias + lane, dbias_acc);
+    if (active && dbias_acc != 0.0f) ndet_scatter_add(dbias, lane, dbias_acc, det);
 }
 
 extern "C" int ndet_density_features_bwd(const float* grad_global_feat, const float* mapped_nhwc, int n_views, int cm, int h, int w,
@@ -158,7 +158,7 @@ extern "C" int ndet_density_features_bwd(const float* grad_global_feat, const fl
     NDET_REQUIRE((int64_t)h * mrow_pitch < ((int64_t)1 << 31), NDET_E_UNSUPPORTED, "%s: one view exceeds 2^31 floats", fn);
     const int n_tiles = (N + BVOX_PER_TILE - 1) / BVOX_PER_TILE;
     hipLaunchKernelGGL(k_density_features_bwd, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, grad_global_feat, mapped_nhwc, n_views, cm, h, w,
-                       mview_pitch, (int)mrow_pitch, bias, points, N, projection, grad_mapped_nhwc, grad_bias, n_tiles);
+                       mview_pitch, (int)mrow_pitch, bias, points, N, projection, grad_mapped_nhwc, grad_bias, n_tiles, g_ndet_deterministic_scatter);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
@@ -208,7 +208,7 @@ __device__ __forceinline__ Taps bilinear_taps(float nx, float ny, int Hs, int Ws
 __global__ __launch_bounds__(256) void k_ray_view_stats_bwd(const float* __restrict__ gglob, const float* __restrict__ pts, int n_points,
                                                             const float* __restrict__ KE, int n_views, float img_h, float img_w,
                                                             const float* __restrict__ feat, int d, int hf, int wf, int64_t fview_pitch,
-                                                            int frow_pitch, float* __restrict__ dfeat) {
+                                                            int frow_pitch, float* __restrict__ dfeat, int det) {
     const int lane = threadIdx.x & 63;
     const int p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // one wave per sample point
     if (p >= n_points) return;
@@ -254,12 +254,12 @@ __global__ __launch_bounds__(256) void k_ray_view_stats_bwd(const float* __restr
                     acc2 = acc2 + (val - mean);
                 } else if (active) {
                     const float gv = (mv ? gm * wgt : 0.0f) + k2 * (2.0f * (val - mean) - (mv ? 2.0f * wgt * dsum : 0.0f));
-                    float* db = dfeat + (int64_t)(r0 + b) * fview_pitch + lane;
+                    const int64_t dbo = (int64_t)(r0 + b) * fview_pitch + lane;     // element index (8-byte elements in the deterministic mode)
                     if (gv != 0.0f) {
-                        if (t.o00 >= 0) unsafeAtomicAdd(db + t.o00, gv * t.w00);
-                        if (t.o01 >= 0) unsafeAtomicAdd(db + t.o01, gv * t.w01);
-                        if (t.o10 >= 0) unsafeAtomicAdd(db + t.o10, gv * t.w10);
-                        if (t.o11 >= 0) unsafeAtomicAdd(db + t.o11, gv * t.w11);
+                        if (t.o00 >= 0) ndet_scatter_add(dfeat, dbo + t.o00, gv * t.w00, det);
+                        if (t.o01 >= 0) ndet_scatter_add(dfeat, dbo + t.o01, gv * t.w01, det);
+                        if (t.o10 >= 0) ndet_scatter_add(dfeat, dbo + t.o10, gv * t.w10, det);
+                        if (t.o11 >= 0) ndet_scatter_add(dfeat, dbo + t.o11, gv * t.w11, det);
                     }
                 }
             }
@@ -283,7 +283,7 @@ extern "C" int ndet_ray_view_stats_bwd(const float* grad_global_feat, const floa
     const int64_t blocks = ((int64_t)n_points + 3) / 4;
     NDET_REQUIRE(blocks < ((int64_t)1 << 31), NDET_E_UNSUPPORTED, "%s: too many points", fn);
     hipLaunchKernelGGL(k_ray_view_stats_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad_global_feat, pts, n_points, KE, n_views,
-                       img_h, img_w, feat_nhwc, d, hf, wf, fview_pitch, (int)frow_pitch, grad_feat_nhwc);
+                       img_h, img_w, feat_nhwc, d, hf, wf, fview_pitch, (int)frow_pitch, grad_feat_nhwc, g_ndet_deterministic_scatter);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }

@@ -1715,7 +1715,8 @@ extern "C" int ndet_measurement_knob(const char* name, int64_t value) {
     NDET_REQUIRE(name, NDET_E_INVALID, "%s: null name", fn);
     if (!strcmp(name, "nt_bytes")) { NDET_REQUIRE(value >= 0, NDET_E_INVALID, "%s: nt_bytes must be >= 0", fn); g_nt_bytes = value; return NDET_OK; }
     if (!strcmp(name, "order2")) { NDET_REQUIRE(value == 0 || value == 1, NDET_E_INVALID, "%s: order2 is 0 or 1", fn); g_order2 = value != 0; return NDET_OK; }
-    ndet_set_error("%s: unknown knob '%s' (nt_bytes, order2)", fn, name);
+    if (!strcmp(name, "deterministic_scatter")) { NDET_REQUIRE(value == 0 || value == 1, NDET_E_INVALID, "%s: deterministic_scatter is 0 or 1", fn); g_ndet_deterministic_scatter = (int)value; return NDET_OK; }
+    ndet_set_error("%s: unknown knob '%s' (nt_bytes, order2, deterministic_scatter)", fn, name);
     return NDET_E_INVALID;
 }
 extern "C" int ndet_amax_slot_floats(void) { return NDET_AMAX_SUB * NDET_AMAX_STRIDE; }

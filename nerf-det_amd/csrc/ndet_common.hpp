@@ -71,6 +71,16 @@ __device__ __forceinline__ bool ndet_project(const float* __restrict__ P, float 
     return ok;
 }
 
+// Gradient scatter of the backward kernels.  Default: float atomics (global_atomic_add_f32) -- fast, but the ORDER of the adds, and with it the last
+// bits of every sum, changes from run to run.  Deterministic mode (tests: ndet_measurement_knob("deterministic_scatter", 1); the caller then hands
+// a zeroed buffer of int64 in place of the float buffer): every contribution is rounded to a multiple of 2^-40 and added as a 64-bit INTEGER --
+// integer addition is associative, so the sum is the same whatever the order (range +-8.4e6, resolution 9e-13; the caller converts back).
+extern int g_ndet_deterministic_scatter;      // host side, set by ndet_measurement_knob, read by the backward launchers
+__device__ __forceinline__ void ndet_scatter_add(float* buf, int64_t idx, float v, int det) {
+    if (det) atomicAdd(reinterpret_cast<unsigned long long*>(buf) + idx, (unsigned long long)(long long)llrintf(v * 0x1p40f));
+    else unsafeAtomicAdd(buf + idx, v);
+}
+
 __device__ __forceinline__ float4 ndet_add4(float4 a, float4 b) {
     return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_ray_stats_packed(const float* __restric
                                                           float img_h, float img_w, const float* __restrict__ rgb4, int H, int W,
                                                           const float* __restrict__ feat, int d, int hf, int wf, int fview_pitch, int frow_pitch,
                                                           float* __restrict__ glob, uint8_t* __restrict__ pixel_mask, int* __restrict__ view_count,
-                                                          const float* __restrict__ gglob, float* __restrict__ dfeat, int nvp) {
+                                                          const float* __restrict__ gglob, float* __restrict__ dfeat, int nvp, int det) {
     extern __shared__ float2 s_rec[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lps = (d >> 2) + (BWD ? 0 : 1);          // lanes per sample
@@ -322,11 +322,11 @@ __global__ __launch_bounds__(256) void k_ray_stats_packed(const float* __restric
                 val = val + v0[t.o11] * t.w11;
                 const bool mv = (vm >> b) & 1ull;
                 const float gv = (mv ? kc.z : 0.0f) + kc.y * (2.0f * (val - kc.x) - (mv ? kc.w : 0.0f));
-                float* dv = dfeat + (r * 64 + b) * fview_pitch + ch;
-                if (t.w00 != 0.0f) unsafeAtomicAdd(dv + t.o00, gv * t.w00);
-                if (t.w01 != 0.0f) unsafeAtomicAdd(dv + t.o01, gv * t.w01);
-                if (t.w10 != 0.0f) unsafeAtomicAdd(dv + t.o10, gv * t.w10);
-                if (t.w11 != 0.0f) unsafeAtomicAdd(dv + t.o11, gv * t.w11);
+                const int64_t dvo = (int64_t)(r * 64 + b) * fview_pitch + ch;      // element index: the deterministic mode's elements are 8 bytes wide
+                if (t.w00 != 0.0f) ndet_scatter_add(dfeat, dvo + t.o00, gv * t.w00, det);
+                if (t.w01 != 0.0f) ndet_scatter_add(dfeat, dvo + t.o01, gv * t.w01, det);
+                if (t.w10 != 0.0f) ndet_scatter_add(dfeat, dvo + t.o10, gv * t.w10, det);
+                if (t.w11 != 0.0f) ndet_scatter_add(dfeat, dvo + t.o11, gv * t.w11, det);
             }
         }
     }
@@ -370,7 +370,7 @@ extern "C" int ndet_ray_view_stats_packed(const float* pts, int n_points, const 
     NDET_REQUIRE((((uintptr_t)rgb_nhwc4 | (uintptr_t)feat_nhwc) & 15) == 0, NDET_E_UNSUPPORTED, "%s: sources must be 16-byte aligned", fn);
     hipLaunchKernelGGL(k_ray_stats_packed<false>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, pts, n_points, KE, n_views, img_h,
                        img_w, rgb_nhwc4, H, W, feat_nhwc, d, hf, wf, (int)fview_pitch, (int)frow_pitch, global_feat, pixel_mask, view_count,
-                       (const float*)nullptr, (float*)nullptr, nvp);
+                       (const float*)nullptr, (float*)nullptr, nvp, 0);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
@@ -387,7 +387,7 @@ extern "C" int ndet_ray_view_stats_packed_bwd(const float* grad_global_feat, con
     NDET_REQUIRE(((uintptr_t)feat_nhwc & 15) == 0, NDET_E_UNSUPPORTED, "%s: features must be 16-byte aligned", fn);
     hipLaunchKernelGGL(k_ray_stats_packed<true>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, pts, n_points, KE, n_views, img_h,
                        img_w, (const float*)nullptr, 2, 2, feat_nhwc, d, hf, wf, (int)fview_pitch, (int)frow_pitch, (float*)nullptr,
-                       (uint8_t*)nullptr, (int*)nullptr, grad_global_feat, grad_feat_nhwc, nvp);
+                       (uint8_t*)nullptr, (int*)nullptr, grad_global_feat, grad_feat_nhwc, nvp, g_ndet_deterministic_scatter);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }

@@ -18,6 +18,7 @@ void ndet_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int g_ndet_deterministic_scatter = 0;      // ndet_common.hpp::ndet_scatter_add
 extern "C" int ndet_version(void) { return 106; }
 extern "C" const char* ndet_last_error(void) { return g_err; }
 

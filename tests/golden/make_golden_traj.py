@@ -1,0 +1,52 @@
+"""Generates tests/golden/train_traj.npz: the per-loss trajectory of 5 optimizer steps (AdamW 2e-4, backbone x0.1, clip 35: config:167-173) of the
+detector on a fixed small scene, computed ON THE CPU with the oracle standing in for the HIP ops (tests/cpu_detector.py) -- deterministic ray
+sampling, the ray draw of step k from RandomState(1000 + k).  tests/test_train_gpu.py holds the GPU training path (HIP autograd Functions, MFMA
+training convolutions, deterministic gradient scatter) to it step by step.
+
+    python tests/golden/make_golden_traj.py          (build container, ~1 min)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+STEPS = 5
+KEYS = ("loss_centerness", "loss_bbox", "loss_cls", "loss_nvs", "loss_depth", "loss")
+
+
+def learnable_scene(device):
+    from test_ddp import _scene
+    scene = _scene(0, device)
+    scene["gt_depths"] = torch.full_like(scene["gt_depths"], 2.0)
+    scene["gt_images"] = torch.ones_like(scene["gt_images"]) * torch.tensor([0.3, 0.5, 0.7], device=device)
+    return scene
+
+
+def main():
+    from cpu_detector import oracle_backed_cpu_ops
+    from test_ddp import _build
+    from nerfdet_amd.train import build_optimizer, train_one_step
+    torch.set_num_threads(8)
+    det = _build(torch.device("cpu"))
+    det.N_rand = 256
+    opt = build_optimizer(det)
+    scene = learnable_scene(torch.device("cpu"))
+    rows, norms = [], []
+    with oracle_backed_cpu_ops() as holder:
+        for k in range(STEPS):
+            holder["rng"] = np.random.RandomState(1000 + k)
+            out = train_one_step(det, scene, opt)
+            rows.append([out["log_vars"][n] for n in KEYS])
+            norms.append(out["grad_norm"])
+            print(k, {n: round(v, 6) for n, v in zip(KEYS, rows[-1])}, "grad norm", round(norms[-1], 4))
+    np.savez(os.path.join(ROOT, "tests", "golden", "train_traj.npz"), keys=np.array(KEYS), losses=np.array(rows, dtype=np.float64),
+             grad_norm=np.array(norms, dtype=np.float64), steps=STEPS, n_rand=256)
+
+
+if __name__ == "__main__":
+    main()
