@@ -285,6 +285,35 @@ def serve_in_flight(det, batch, steps, n_streams=2):
     return steps / dt
 
 
+def train_probe(det_gpu, batch):
+    """BASELINE configs[2]'s per-rank training step (40 source + 10 NeRF target views 240x320, 40x40x16 voxels, 2048 rays x 64 samples, five
+    losses, backward, clip, AdamW) timed by tools/bench_train.py in a CHILD process after everything else has been measured (this process
+    first drops its model and cache: the child gets the card to itself).  Not the headline -- the step the reference trains with, in the
+    driver's record.  Returns {ms, median_ms, dtype, roofline_all_convolutions, ...} or {error}."""
+    import gc
+    import subprocess
+    det_gpu.to("cpu")
+    batch.clear()
+    gc.collect()
+    torch.cuda.empty_cache()
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_train.py"), "--steps", "8", "--warmup", "3"], capture_output=True, text=True,
+                           timeout=420, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")})
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"tools/bench_train.py rc={r.returncode}: {r.stderr[-300:]}"}
+        d = json.loads(lines[-1])
+        keep = {"ms": d["ms_per_step"], "median_ms": d["median_ms"], "p10_ms": d["p10_ms"], "p90_ms": d["p90_ms"], "steps": d["steps"], "warmup": d["warmup"],
+                "dtype": d["dtype"], "scenes_per_s": d["value"], "workload": d["config"]["workload"], "log_vars": d["log_vars"], "peak_mem_GB": d["peak_mem_GB"],
+                "note": "tools/bench_train.py --steps 8 --warmup 3 in a child process after the timed region; one rank, no DDP"}
+        for k in ("roofline", "roofline_all_convolutions", "roofline_k4_forward", "roofline_k4_backward"):
+            if k in d:
+                keep[k] = {kk: vv for kk, vv in d[k].items() if kk != "per_kernel"}
+        return keep
+    except Exception as e:      # the extra figure must never cost the headline line
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -292,6 +321,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-probe", action="store_true", help="skip the cfg3 training-step figure (tools/bench_train.py in a child process after the "
+                    "timed region; BENCH records then carry a driver-run training number: key train_cfg3_step)")
     ap.add_argument("--no-serving", action="store_true", help="skip the extra two-scenes-in-flight loop after the timed region (profiling runs: its "
                     "overlapped launches would enter the per-kernel averages)")
     ap.add_argument("--graph", action="store_true",
@@ -562,6 +593,8 @@ def main():
             out["six_product_bf16x3_arithmetic"] = six
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, build_model(w), batch_cpu)
+        if not (args.no_train_probe or args.graph or args.no_serving) and world == 1 and args.workload == "cfg2":
+            out["train_cfg3_step"] = train_probe(det_gpu, batch)
         print(json.dumps(out))
     if grouped:
         torch.distributed.destroy_process_group()
