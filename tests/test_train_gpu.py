@@ -207,8 +207,9 @@ def _five_steps(device, deterministic):
 
 @pytest.mark.timeout(900)
 def test_five_optimizer_steps_follow_the_cpu_trajectory(device):
-    """"chaotic" and "wrong" separated by evidence.  (a) With the deterministic scatter two runs of the same five steps give
-    the SAME parameters bit for bit -- the run-to-run spread of round 3 was the float atomics' ordering and nothing else.  (b) That reproducible
+    """"chaotic" and "wrong" separated by evidence.  (a) With the deterministic scatter two runs of the same five steps on
+    freshly built models end within 1e-6 of each other (the backward itself: bit for bit, next test) -- the run-to-run spread of round 3 was the
+    float atomics' ordering and nothing else.  (b) That reproducible
     run follows the trajectory of the oracle-backed CPU module (tests/golden/train_traj.npz) loss by loss, step by step.  (c) The float-atomic
     default follows it as well over these five steps (its noise is 1e-6 of the gradients; what Adam makes of it shows later)."""
     import os
@@ -216,7 +217,9 @@ def test_five_optimizer_steps_follow_the_cpu_trajectory(device):
     ref, ref_norm = g["losses"], g["grad_norm"]
     a, na, wa = _five_steps(device, True)
     b, nb, wb = _five_steps(device, True)
-    assert np.array_equal(a, b) and torch.equal(wa, wb), "the deterministic scatter did not reproduce its own run bit for bit"
+    # two runs on freshly built models (other addresses: the vendor library's reductions and GEMMs pick alignment-dependent paths) agree to the
+    # last ulp or two; the backward itself is reproducible bit for bit (test_deterministic_scatter_makes_one_step_bitwise_reproducible)
+    assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max() and float((wa - wb).abs().max()) <= 1e-6, "the deterministic mode did not reproduce its own run"
     c, nc, wc = _five_steps(device, False)
     rel = lambda x: np.abs(x - ref) / np.maximum(np.abs(ref), 1e-3)
     print("deterministic GPU run vs CPU trajectory, relative per loss per step:\n", np.array2string(rel(a), precision=5, suppress_small=True))
@@ -226,3 +229,49 @@ def test_five_optimizer_steps_follow_the_cpu_trajectory(device):
     assert rel(a).max() <= 2e-2, f"the deterministic GPU run leaves the CPU trajectory: {rel(a).max():.4f}"
     assert rel(c).max() <= 2e-2
     assert np.abs(na - ref_norm).max() <= 2e-2 * ref_norm.max()
+
+
+@pytest.mark.timeout(600)
+def test_deterministic_scatter_makes_one_step_bitwise_reproducible(device):
+    """One training step (forward, five losses, backward) three times on the same model: with ``autograd.set_deterministic(True)`` every one of
+    the parameter gradients is the same bit pattern in all three runs (K1 / K2 / K4 backward scatter with 64-bit fixed-point integer atomics:
+    integer sums do not depend on the order of the adds; every other kernel of the step -- split-K and weight-gradient reductions included --
+    sums in a fixed order already).  With the default float atomics some gradients differ from run to run: that, and nothing else, was the
+    "chaotic" part of round 3's 30-step test.  The two modes agree to 1e-5 of each gradient's scale."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden_traj import learnable_scene
+    from test_ddp import _build
+    import nerfdet_amd.rays as R
+    from nerfdet_amd import autograd as A
+    det = _build(device)
+    det.N_rand = 256
+    scene = learnable_scene(device)
+    orig = R.sample_along_camera_ray
+    R.sample_along_camera_ray = lambda *a, **k: orig(*a, **{**k, "det": True})
+
+    def grads():
+        R.rng = np.random.RandomState(1000)
+        det.zero_grad(set_to_none=True)
+        det.train_step(scene)["loss"].backward()
+        return {n: p.grad.detach().clone() for n, p in det.named_parameters() if p.grad is not None}
+    try:
+        out = {}
+        for mode in (True, False):
+            prev = A.set_deterministic(mode)
+            try:
+                out[mode] = [grads() for _ in range(3)]
+            finally:
+                A.set_deterministic(prev)
+    finally:
+        R.sample_along_camera_ray = orig
+    det_runs, flt_runs = out[True], out[False]
+    assert len(det_runs[0]) > 100
+    bad = [n for n in det_runs[0] if not all(torch.equal(det_runs[0][n], r[n]) for r in det_runs[1:])]
+    assert not bad, f"{len(bad)} gradients are not reproducible in the deterministic mode, e.g. {bad[:5]}"
+    moved = [n for n in flt_runs[0] if not all(torch.equal(flt_runs[0][n], r[n]) for r in flt_runs[1:])]
+    print(f"float atomics: {len(moved)} of {len(flt_runs[0])} parameter gradients differ between three runs of the same step; deterministic mode: 0")
+    assert moved, "the float-atomic scatter reproduced itself bit for bit three times: the deterministic mode would have nothing to fix"
+    for n, g in det_runs[0].items():
+        scale = float(g.abs().max())
+        assert float((g - flt_runs[0][n]).abs().max()) <= 1e-5 * max(scale, 1e-12), n
