@@ -34,14 +34,25 @@ def _dense_nhwc(t):
 # them to 64-bit fixed-point integer atomics (csrc/ndet_common.hpp::ndet_scatter_add: contributions rounded to multiples of 2^-40, integer sums are
 # order-independent): bitwise reproducible gradients, ~2x the scatter time and twice the buffer.  The default stays the fast float path.
 DETERMINISTIC = False
+_TORCH_PREV = None
 _FIX = 2.0 ** -40
 
 
 def set_deterministic(on: bool) -> bool:
     """Switch the gradient scatter of K1 / K2 / K4 backward to the order-independent fixed-point form; returns the previous setting."""
-    global DETERMINISTIC
+    global DETERMINISTIC, _TORCH_PREV
     prev, DETERMINISTIC = DETERMINISTIC, bool(on)
     check(_lib.load().ndet_measurement_knob(b"deterministic_scatter", int(DETERMINISTIC)), "measurement_knob")
+    # the vendor library's part of the step (the data gradient of the stride-2 convolutions, ATen's index / scatter ops): its own deterministic
+    # algorithms -- measured: without this 33 of 122 parameter gradients still differed between runs, all upstream of the library's stride-2 dgrad
+    if DETERMINISTIC and _TORCH_PREV is None:
+        _TORCH_PREV = (torch.backends.cudnn.deterministic, torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled())
+        torch.backends.cudnn.deterministic = True
+        torch.use_deterministic_algorithms(True, warn_only=True)
+    elif not DETERMINISTIC and _TORCH_PREV is not None:
+        torch.backends.cudnn.deterministic = _TORCH_PREV[0]
+        torch.use_deterministic_algorithms(_TORCH_PREV[1], warn_only=_TORCH_PREV[2])
+        _TORCH_PREV = None
     return prev
 
 

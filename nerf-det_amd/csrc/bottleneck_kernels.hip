@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
 
     // conv2's weight fragments (one output channel per lane, 4 K slices x 2 planes per tap) stream from L2 three taps ahead: a ring of four sets.
     // The first three are requested here, before phase B: they land while the halo image is written.
-    const int wm2 = wave >> 1, wn2 = wave & 1;       // phase C: 32 output pixels x 32 channels per wave
+    const int wm2 = wave >> 1, wn2 = wave & 1;       // phases C / D: tap group (C) and finished pixel tile (D), channel half
     bf16x8 fw[4][4][2];                               // [ring set][k slice][plane]
     const uint16_t* w2p = p.w2 + (int64_t)(wn2 * 32 + frow) * CBK + fk;
     auto load_w2 = [&](auto S, int tap) {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
             for (int pl = 0; pl < 2; ++pl)
                 fw[s][ks][pl] = *reinterpret_cast<const bf16x8*>(w2p + ((((int64_t)tap * 2 + (ks >> 1)) * 2 + pl) * BT_MID) * CBK + (ks & 1) * 16);
     };
-    static_for<0, 3>([&](auto T) { load_w2(T, decltype(T)::value); });
+    static_for<0, 3>([&](auto T) { load_w2(T, wm2 * 5 + decltype(T)::value); });      // the first three taps of this wave's tap group (phase C)
 
     // workgroup maximum of a wave-level value (uniform result; a barrier inside)
     auto wg_maximum = [&](float v) -> float {
@@ -252,30 +252,47 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
     STAMP(2);
 
     // ---------------- phase C: conv2 (3x3, 64 -> 64) out of the halo image ----------------
-    f32x16 acc2[2];                                   // two accumulators taken in turn: no MFMA waits for the one before it
+    // A wave owns 32 output channels (wn2) and HALF OF THE TAPS (group tg: taps 0-4 or 5-8) for all 64 pixels: every W2 fragment is fetched by
+    // exactly one wave (with 32 pixels x all taps per wave each fragment was fetched twice: 295 KB of the 680 KB a patch pulled from L2).  The
+    // two waves of a channel half then swap the partial sums of the pixel tile the other one finishes.
+    const int tg = wm2;
+    f32x16 acc2[2];                                   // the two 32-pixel tiles
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[a][r] = 0.f;
     {
-        const int po = wm2 * 32 + frow, py = po >> 4, px = po & 15;
-        static_for<0, 9>([&](auto T) {
-            constexpr int tap = decltype(T)::value;
-            if constexpr (tap + 3 < 9) load_w2(ic<(tap + 3) % 4>{}, tap + 3);
-            constexpr int dy = tap / 3, dx = tap % 3;
-            const int irow = (py + dy) * BT_HW + px + dx;
-            const uint16_t* ya = Y1 + irow * BT_MID;
+        static_for<0, 5>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const int tap = tg * 5 + i;                               // wave-uniform
+            if (tap < 9) {
+                if (i + 3 < 5 && tap + 3 < 9) load_w2(ic<(i + 3) % 4>{}, tap + 3);
+                const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 fa[2];
+                for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) fa[pl] = *reinterpret_cast<const bf16x8*>(ya + pl * Y1PL + (((2 * ks + fh) ^ (irow & 7)) << 3));
-                f32x16& cc = acc2[ks & 1];
-                cc = spl_mfma32<1>(fa[0], fw[tap % 4][ks][1], cc);
-                cc = spl_mfma32<1>(fa[1], fw[tap % 4][ks][0], cc);
-                cc = spl_mfma32<1>(fa[0], fw[tap % 4][ks][0], cc);
+                    for (int a = 0; a < 2; ++a) {
+                        const int po = a * 32 + frow;
+                        const int irow = ((po >> 4) + dy) * BT_HW + (po & 15) + dx;
+                        bf16x8 fa[2];
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl)
+                            fa[pl] = *reinterpret_cast<const bf16x8*>(Y1 + pl * Y1PL + irow * BT_MID + (((2 * ks + fh) ^ (irow & 7)) << 3));
+                        acc2[a] = spl_mfma32<1>(fa[0], fw[i % 4][ks][1], acc2[a]);
+                        acc2[a] = spl_mfma32<1>(fa[1], fw[i % 4][ks][0], acc2[a]);
+                        acc2[a] = spl_mfma32<1>(fa[0], fw[i % 4][ks][0], acc2[a]);
+                    }
+                }
             }
         });
+        // swap: this wave finishes pixel tile tg; its partial sums of the other tile go to the partner (same channel half, other tap group)
+        float* xch = reinterpret_cast<float*>(lds16);                  // 4 waves x 16 registers x 64 lanes (16 KB over the staging planes; Y2 comes later)
+        const int partner = (1 - tg) * 2 + wn2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(partner * 16 + r) * 64 + lane] = tg ? acc2[0][r] : acc2[1][r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[0][r] = (tg ? acc2[1][r] : acc2[0][r]) + xch[(wave * 16 + r) * 64 + lane];
     }
     STAMP(3);
 
@@ -329,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
         float m = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float v = fmaxf(((acc2[0][r] + acc2[1][r]) * osc2) * sc + sh, 0.f);
+            const float v = fmaxf((acc2[0][r] * osc2) * sc + sh, 0.f);
             acc2[0][r] = v;
             m = fmaxf(m, v);
         }
