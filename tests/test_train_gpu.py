@@ -222,14 +222,21 @@ def test_five_optimizer_steps_follow_the_cpu_trajectory(device):
     assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max() and float((wa - wb).abs().max()) <= 1e-6, "the deterministic mode did not reproduce its own run"
     c, nc, wc = _five_steps(device, False)
     rel = lambda x: np.abs(x - ref) / np.maximum(np.abs(ref), 1e-3)
+    # The yardstick: how far the CPU trajectory moves when every weight is perturbed by 1e-6 relative (tests/golden/make_golden_traj.py, maximum of
+    # three draws): 0.4 % at step 1, 2 - 5 % at step 3, 55 % of the classification loss at step 4 -- Adam's sign-like first steps and the batch
+    # statistics of a one-scene batch amplify rounding-level differences by four orders of magnitude in four steps.  A GPU run (other summation
+    # orders in every kernel) cannot stay closer to the trajectory than the trajectory stays to itself: the bar is 3 x that spread, with a floor of
+    # 1e-3; the first step (same weights on both sides, nothing amplified yet) must agree to 1e-5.
+    spread = g["spread_1e6"] / np.maximum(np.abs(ref), 1e-3)
+    bar = np.maximum(3.0 * spread, 1e-3)
     print("deterministic GPU run vs CPU trajectory, relative per loss per step:\n", np.array2string(rel(a), precision=5, suppress_small=True))
     print("float-atomic GPU run vs CPU trajectory:\n", np.array2string(rel(c), precision=5, suppress_small=True))
+    print("the CPU trajectory's own spread under 1e-6 weight perturbations:\n", np.array2string(spread, precision=5, suppress_small=True))
     print("gradient norms (CPU | deterministic | atomics):", np.round(ref_norm, 3), np.round(na, 3), np.round(nc, 3))
-    assert rel(a)[0].max() <= 1e-3, "the first step's losses (same weights on both sides) differ from the CPU module's"
-    assert rel(a).max() <= 2e-2, f"the deterministic GPU run leaves the CPU trajectory: {rel(a).max():.4f}"
-    assert rel(c).max() <= 2e-2
-    assert np.abs(na - ref_norm).max() <= 2e-2 * ref_norm.max()
-
+    assert rel(a)[0].max() <= 1e-5, "the first step's losses (same weights on both sides) differ from the CPU module's"
+    assert (rel(a) <= bar).all(), f"the deterministic GPU run leaves the CPU trajectory by more than 3 x the trajectory's own 1e-6 sensitivity:\n{rel(a) / bar}"
+    assert (rel(c) <= bar).all(), f"the float-atomic GPU run leaves the CPU trajectory:\n{rel(c) / bar}"
+    assert abs(na[0] - ref_norm[0]) <= 1e-3 * ref_norm[0]
 
 @pytest.mark.timeout(600)
 def test_deterministic_scatter_makes_one_step_bitwise_reproducible(device):
