@@ -176,12 +176,16 @@ class VanillaNeRFRadianceField(nn.Module):
         b = self.mlp.base
         n_in = 63 + features.shape[-1]
         width = (n_in + 31) // 32 * 32
-        rows = ops.posenc_concat(x.reshape(n, 3).t().contiguous(), features.reshape(n, -1), pad_to=width)
-        h = rows
-        for i, lin in enumerate(b.hidden_layers):
-            h = linear_rows(h, packed_linear(lin, pad_in_to=width if i == 0 else 0), relu=1)
+        pts = x.reshape(n, 3).t().contiguous()
+        rows = ops.posenc_concat(pts, features.reshape(n, -1), pad_to=width)       # (the bottleneck layer below re-joins them)
         out = self.mlp.sigma_layer.output_layer
-        _, raw_sigma = ops.sigma_head(h, rows, n_in, out.weight, out.bias, want_raw=True)
+        if self.fused_ok(width):      # trunk + sigma layer in one launch, the 256-wide rows written once (for the bottleneck layer)
+            _, raw_sigma, h = ops.point_mlp_alpha(pts, features.reshape(n, -1), self._fused_layers(width), out.weight, out.bias, want_raw=True, want_h=True)
+        else:
+            h = rows
+            for i, lin in enumerate(b.hidden_layers):
+                h = linear_rows(h, packed_linear(lin, pad_in_to=width if i == 0 else 0), relu=1)
+            _, raw_sigma = ops.sigma_head(h, rows, n_in, out.weight, out.bias, want_raw=True)
         wide = (h.shape[1] + n_in + 31) // 32 * 32
         hc = torch.zeros((n, wide), dtype=torch.float32, device=h.device)
         hc[:, :h.shape[1]] = h
