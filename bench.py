@@ -364,7 +364,7 @@ def main():
     state = {"step": 0}
     # ~150 conv launches per step: their event pairs cost ~2 % of the step, so they are sampled on every 4th timed step; the two
     # gather kernels and the five stage marks are recorded on every step
-    rec = trace.Recorder(sample=lambda name: (not name.startswith(("k_conv", "f32:", "bf16x3:", "f16x2:", "bf16:"))) or state["step"] % 4 == 0)
+    rec = trace.Recorder(sample=lambda name: (not name.startswith(("k_conv", "k_bottleneck", "k_point_mlp", "f32:", "bf16x3:", "f16x2:", "bf16:"))) or state["step"] % 4 == 0)
 
     if args.graph:
         from nerfdet_amd.graphed import GraphedForwardTest

@@ -110,7 +110,7 @@ def main():
     opt = build_optimizer(model)
     state = {"step": 0}
     # ~450 convolution launches per step (forward, data and weight gradients): their event pairs are sampled on every 4th timed step
-    rec = trace.Recorder(sample=lambda name: (not name.startswith(("k_conv", "f32:", "bf16x3:", "bf16:", "f16x2:"))) or state["step"] % 4 == 0)
+    rec = trace.Recorder(sample=lambda name: (not name.startswith(("k_conv", "k_bottleneck", "k_point_mlp", "f32:", "bf16x3:", "bf16:", "f16x2:"))) or state["step"] % 4 == 0)
     for _ in range(args.warmup):
         out = train_one_step(model, data, opt)
     trace.recorder = rec
