@@ -350,8 +350,10 @@ int ndet_conv_ndhwc_arith(const float* in, const uint16_t* w_planes, float* out,
 /* ndet_conv_ndhwc_arith with the RANGE GUARD of the fp16-pair arithmetic (arith 1; ignored otherwise).  The activation scale of that arithmetic
  * is per tensor, so beside its fp32-class relative error an output carries an absolute floor of at most
  *     2^-39 max|in| * guard_l1,      guard_l1 = max_j |scale_j| (sum_k |w_jk| + max|w| #{k: 0 < |w_jk| < 2^-16 max|w|})      (host, once per pack)
- * whatever the distribution inside the tensor (csrc/conv_common.hpp::conv_guard_check).  max|in| is known on the device at kernel entry: when
- * the floor exceeds guard_tol the launch ORs 1 into *guard (device word, zeroed by the caller per scene).  The caller reads the word with the
+ * whatever the distribution inside the tensor (csrc/conv_common.hpp::conv_guard_check).  max|in| is known on the device at kernel entry, and so is
+ * the smallest maximum any workgroup tile of the input committed (word 1 of the amax sub-slots): when the floor exceeds guard_tol AND that tile
+ * minimum lies below 2^-16 of max|in| (a part of the tensor really is outside the fp16-pair window; a uniformly large tensor is not), the launch ORs
+ * 1 into *guard (device word, zeroed by the caller per scene).  The caller reads the word with the
  * detections (ndet_nms_pack_detections) and repeats such a scene on the six-product bf16x3 arithmetic.  Same reference modules as
  * ndet_conv_ndhwc_split (mmdet3d/models/necks/imvoxelnet.py:36-67,233-260, dense_heads/imvoxel_head_v2.py:45-49, the backbone behind
  * detectors/nerfdet.py:140); the tensor that first needed it: the sigma-MLP rows of nerfdet.py:236-243. */
@@ -362,7 +364,7 @@ int ndet_conv_ndhwc_guarded(const float* in, const uint16_t* w_planes, float* ou
                             unsigned* guard, void* stream);
 
 /* ndet_conv_chain_arith with the range guard (see ndet_conv_ndhwc_guarded): guard_l1 belongs to w_planes and max|in|, guard_l1_3 to w3_planes and
- * each workgroup's own maximum of the intermediate.  The bottleneck tail of the backbone called at mmdet3d/models/detectors/nerfdet.py:140. */
+ * the chained product (reserved: its operand is scaled by each workgroup's own maximum, which needs no check).  The bottleneck tail of the backbone called at mmdet3d/models/detectors/nerfdet.py:140. */
 int ndet_conv_chain_guarded(const float* in, const uint16_t* w_planes, int D, int H, int W, int Cin, int Cmid, const int* kernel,
                             const int* stride, const int* pad, const float* scale1, const float* shift1, const uint16_t* w3_planes,
                             int Cout, const float* scale3, const float* shift3, const float* residual, int relu3, float* out,

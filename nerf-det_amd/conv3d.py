@@ -162,7 +162,8 @@ def amax_of(x: torch.Tensor) -> torch.Tensor:
 
 # ---- range guard of the fp16-pair arithmetic (csrc/conv_common.hpp::conv_guard_check) ----
 # Every fp16-pair launch compares its absolute error floor, 2^-39 max|in| * guard_l1, with GUARD_TOL on the device and raises the scene's guard
-# word when it is exceeded.  The detector zeroes the word at the start of a scene (guard_begin), the word reaches the host with the scene's
+# word when it is exceeded AND the smallest workgroup-tile maximum recorded for its input lies below 2^-16 of max|in| (some part of the tensor really
+# is outside the fp16-pair window; a uniformly large tensor -- ResNet-101 without calibrated statistics: activations of 1e6 everywhere -- is not).  The detector zeroes the word at the start of a scene (guard_begin), the word reaches the host with the scene's
 # detections (head.simple_test_fused: header word 3 of the packed picks, no extra copy or sync), and a scene whose word is set is repeated on the
 # six-product bf16x3 arithmetic, whose operands are exact (detector.simple_test).  Other callers read it with guard_tripped() (synchronises).
 GUARD_ENABLED = True

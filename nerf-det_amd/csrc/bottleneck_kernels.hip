@@ -92,7 +92,11 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
     const int y0 = ty * BT_TH, x0 = tx * BT_TW;
     const float amax_in = conv_amax_read(p.amax_in);
     const float xs = conv_xscale_of(amax_in);
-    if (p.guard && blockIdx.x == 0 && tid == 0 && (amax_in * p.g1 * 0x1p-39f > p.gtol || (DS && amax_in * p.gd * 0x1p-39f > p.gtol))) atomicOr(p.guard, 1u);
+    if (p.guard && blockIdx.x == 0) {          // range guard of conv1 (and the downsample branch) on x: conv_common.hpp::conv_guard_check's two conditions
+        const float tmin = conv_tilemin_read(p.amax_in);
+        const float g = DS ? fmaxf(p.g1, p.gd) : p.g1;
+        if (tid == 0 && amax_in * g * 0x1p-39f > p.gtol && tmin < amax_in * 0x1p-16f) atomicOr(p.guard, 1u);
+    }
 
     if (tid < BT_AROWS) {
         const int hy = tid / BT_HW, hx = tid - hy * BT_HW;
@@ -234,7 +238,6 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
             }
         ymax1 = wg_maximum(m);
         const float ys1 = conv_xscale_of(ymax1);
-        if (p.guard && tid == 0 && ymax1 * p.g2 * 0x1p-39f > p.gtol) atomicOr(p.guard, 1u);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -352,7 +355,6 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_f16x2(const BottleneckPar
         }
         ymax2 = wg_maximum(m);           // (its barriers: every wave has left phase A's staging planes, which Y2 overwrites)
         const float ys2 = conv_xscale_of(ymax2);
-        if (p.guard && tid == 0 && ymax2 * p.g3 * 0x1p-39f > p.gtol) atomicOr(p.guard, 1u);
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const int row = wm2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;

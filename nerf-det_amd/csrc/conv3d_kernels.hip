@@ -202,9 +202,14 @@ __global__ __launch_bounds__(256) void k_conv3d_splitk_reduce(const float* __res
                                                               float* __restrict__ amax_out) {
     // VEC = 4 when Cout % 4 == 0: one float4 per thread and pass
     const bool vec = (Cout & 3) == 0;
-    const int64_t step = (int64_t)gridDim.x * blockDim.x * (vec ? 4 : 1);
+    // one contiguous range of the output per workgroup (not a grid-stride walk): the maximum a workgroup commits is then the maximum of a region,
+    // as the range guard's tile minimum assumes (conv_common.hpp::conv_tilemin_read)
+    const int64_t unit = vec ? 4 : 1, units = (MN + unit - 1) / unit;
+    const int64_t per = (units + gridDim.x - 1) / gridDim.x;
+    const int64_t hi = ((int64_t)blockIdx.x * per + per < units ? (int64_t)blockIdx.x * per + per : units) * unit;
+    const int64_t step = (int64_t)blockDim.x * unit;
     float mx = 0.0f;
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * (vec ? 4 : 1); i < MN; i += step) {
+    for (int64_t i = ((int64_t)blockIdx.x * per + threadIdx.x) * unit; i < hi && i < MN; i += step) {
         if (vec) {
             float4 v = *reinterpret_cast<const float4*>(partial + i);
             for (int s = 1; s < splits; ++s) {

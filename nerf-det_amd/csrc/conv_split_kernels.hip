@@ -378,8 +378,8 @@ __global__ __launch_bounds__(256, MID == 64 ? (SCH == 1 ? CHAIN64_F16_WGS : 3) :
         ymax = fmaxf(fmaxf(wg_max[0], wg_max[1]), fmaxf(wg_max[2], wg_max[3]));
         ys = conv_xscale_of(ymax);
         osc3 = conv_xinv_of(ymax) * c.w3inv;
-        // range guard of the chained GEMM: its operand scale is this workgroup's own maximum, so is its floor (conv_guard_check)
-        if (p.guard && tid == 0 && ymax * c.guard_l1 * 0x1p-39f > p.guard_tol) atomicOr(p.guard, 1u);
+        // (no range guard for the chained GEMM: its operand scale is this workgroup's own maximum -- already the granularity at which the guard
+        // looks for parts of a tensor below the fp16-pair window, conv_guard_check)
     }
     float omax = 0.0f;
     // ---- the intermediate's split, into LDS as the A operand of the chained GEMM ----
@@ -1921,8 +1921,12 @@ extern "C" int ndet_conv_ndhwc_arith(const float* in, const uint16_t* w_planes, 
 
 // max |x| of a tensor into a zeroed slot: the amax_in of a fp16-pair convolution whose input was not written by one of the convolution kernels
 __global__ __launch_bounds__(256) void k_amax(const float* __restrict__ x, int64_t n4, int64_t n, float* __restrict__ slot) {
+    // every workgroup takes ONE contiguous range of the tensor: its maximum is the maximum of a region (a few rows / voxels), which is what the range
+    // guard's tile minimum wants to see (conv_tilemin_read) -- a grid-stride walk would make every workgroup's maximum the tensor's
+    const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
     float mx = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }

@@ -324,21 +324,34 @@ def test_range_guard_trips_exactly_when_the_floor_exceeds_the_tolerance(device):
         assert not C.guard_tripped(device)                                            # the exact-operand arithmetic has no floor to report
         err_b3 = float((y3.cpu().double() - refb)[far].abs().max())
         assert err_b3 <= 1e-4 and err_f16 > 10 * err_b3, (err_f16, err_b3)            # what the guard is there to catch
-        # the threshold itself: scale the input so that the floor sits just below / just above the tolerance
-        amax = float(x.abs().max())
+        # the two conditions one at a time.  (1) the floor against the tolerance, on a tensor that does have a part far below its maximum (the second half of
+        # the grid 1e-7 times the first): scaled so that the floor sits just below / just above the tolerance
+        xd = x.clone()
+        xd[3:] *= 1.0e-7
+        amax = float(xd.abs().max())
         for factor, want in ((0.5, False), (2.0, True)):
             s = factor * C.GUARD_TOL * 2.0 ** 39 / (l1 * amax)
             C.guard_begin(device)
-            _run(C, "f16x2", x * s, pk, None, 1, device)
+            _run(C, "f16x2", xd * s, pk, None, 1, device)
             assert C.guard_tripped(device) == want, (factor, s)
+        # (2) a UNIFORMLY large tensor (a deep un-normalised network: activations of 1e7 everywhere) is inside the fp16-pair window everywhere: its
+        # floor is far above the absolute tolerance and far below its own fp32-class error -- no reason to leave the fast arithmetic
+        C.guard_begin(device)
+        yu = _run(C, "f16x2", x * 1.0e7, pk, None, 1, device)
+        assert not C.guard_tripped(device)
+        assert _rel_rms(yu, _reference(conv.cpu(), bn.cpu(), x * 1.0e7, None, 1)) < 1e-6
 
 
-def test_range_guard_of_the_chained_bottleneck_uses_the_workgroups_own_maximum(device):
+def test_range_guard_of_the_chained_bottleneck(device):
+    """The chained kernel checks its FIRST convolution against the input tensor (floor and tile minimum, as every launch); the chained 1x1 product
+    scales its operand by the workgroup's own maximum -- already the granularity the guard looks at -- and needs no check of its own."""
     from nerfdet_amd import conv3d as C
     torch.manual_seed(12)
     c2 = nn.Conv2d(64, 64, 3, 1, 1, bias=False); b2 = nn.BatchNorm2d(64).eval()
     c3 = nn.Conv2d(64, 256, 1, bias=False); b3 = nn.BatchNorm2d(256).eval()
     x = torch.relu(torch.randn(2, 24, 32, 64))
+    xb = x.clone()
+    xb[0] *= 3.0e7                                      # one of the two maps 3e7 times brighter than the other
     with torch.no_grad():
         for m in (c2, b2, c3, b3):
             m.to(device)
@@ -348,10 +361,11 @@ def test_range_guard_of_the_chained_bottleneck_uses_the_workgroups_own_maximum(d
             C.guard_begin(device)
             C.conv2d_chain_nhwc(x.to(device), pk2, pk3, relu=1)
             assert not C.guard_tripped(device)
-            b2.weight.mul_(3.0e7)                       # the INTERMEDIATE becomes huge (a BatchNorm-folded outlier), the input stays ordinary
-            pk2 = C.packed([c2], b2)
             C.guard_begin(device)
-            C.conv2d_chain_nhwc(x.to(device), pk2, pk3, relu=1)
+            C.conv2d_chain_nhwc((x * 3.0e7).to(device), pk2, pk3, relu=1)      # uniformly large: inside the window everywhere
+            assert not C.guard_tripped(device)
+            C.guard_begin(device)
+            C.conv2d_chain_nhwc(xb.to(device), pk2, pk3, relu=1)
             assert C.guard_tripped(device)
         finally:
             C.set_arithmetic(prev)
