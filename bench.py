@@ -538,7 +538,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"f32": "f32", "f16x2": "f32 (convolutions: fp32 operands as hi + lo fp16 pairs of the power-of-two pre-scaled tensors, three products per "
-                               "multiply on the fp16 MFMA, fp32 accumulate; error against fp64 at or below the six-product bf16x3 form's)",
+                               "multiply on the fp16 MFMA, fp32 accumulate; error against fp64 at or below the six-product bf16x3 form's; a device-side range "
+                               "guard repeats a scene on bf16x3 when part of a tensor falls outside the pair's window: range_guard_trips)",
                       "bf16x3": "f32 (convolutions: fp32 operands as exact 3-term bf16 sums on the bf16 MFMA, fp32 accumulate)",
                       "bf16": "bf16 (convolution operands rounded to bf16 on the MFMA, fp32 accumulate; activations, projection, aggregation, "
                               "NMS fp32 -- SURVEY.md 0.1)"}[C3.ARITHMETIC],
