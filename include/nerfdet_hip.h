@@ -405,11 +405,16 @@ int ndet_bn_relu_maxpool_nhwc(const float* x, const float* scale, const float* s
  * w_planes: ndet_stem_pack_weights of the (64,3,7,7) weight; out (N, PH, PW, 64) channels-last, PH = ((H-1)/2+1 - 1)/2 + 1.
  * Arithmetic of ndet_conv_ndhwc_split (fp32 operands as exact sums of three bf16 terms, six MFMA products). */
 int ndet_stem_pack_weights(const float* w_64x3x7x7, uint16_t* planes /* (3, 64, 176) */, void* stream);
+/* ... and its fp16-pair form (two fp16 planes of w * scale, scale a power of two chosen by the caller from max |w|): ndet_stem_conv_bn_relu_maxpool
+ * with w_inv_scale = 1 / scale then issues three fp16 MFMA products per multiply, the image patch scaled by the power of two of its own maximum
+ * inside the kernel (same conv1 / bn1 / relu / maxpool of mmdet's ResNet behind mmdet3d/models/detectors/nerfdet.py:140). */
+int ndet_stem_pack_weights_f16x2(const float* w_64x3x7x7, float scale, uint16_t* planes /* (2, 64, 176) */, void* stream);
 
-/* The launch itself (see above; conv1 / bn1 / relu / maxpool behind mmdet3d/models/detectors/nerfdet.py:140).  out_amax (may be null): max |out|
+/* The launch itself (see above; conv1 / bn1 / relu / maxpool behind mmdet3d/models/detectors/nerfdet.py:140).  w_inv_scale: 0 for the bf16x3 planes of
+ * ndet_stem_pack_weights, else 1 / scale of ndet_stem_pack_weights_f16x2.  out_amax (may be null): max |out|
  * into a zeroed amax slot -- the first bottleneck's fp16-pair scale without another pass over the 61 MB. */
 int ndet_stem_conv_bn_relu_maxpool(const float* images, int N, int H, int W, int64_t stride_n, int64_t stride_c, int64_t stride_y,
-                                   int64_t stride_x, const uint16_t* w_planes, const float* scale, const float* shift, float* out, float* out_amax,
+                                   int64_t stride_x, const uint16_t* w_planes, float w_inv_scale, const float* scale, const float* shift, float* out, float* out_amax,
                                    void* stream);
 
 /* ---- input contract: what the data pipeline hands to nerfdet.forward_*, from decoded,

@@ -78,7 +78,8 @@ SIGNATURES = {
     "ndet_normalize_views": ([_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P], c_int),
     "ndet_target_rays": ([_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
     "ndet_stem_pack_weights": ([_P, _P, _P], c_int),
-    "ndet_stem_conv_bn_relu_maxpool": ([_P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P], c_int),
+    "ndet_stem_conv_bn_relu_maxpool": ([_P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, _P, c_float, _P, _P, _P, _P, _P], c_int),
+    "ndet_stem_pack_weights_f16x2": ([_P, c_float, _P, _P], c_int),
     "ndet_wgrad_dy_planes": ([_P, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_relu_affine_bwd": ([_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P], c_int),
     "ndet_wgrad_split": ([_P] + [c_int] * 4 + [_P, _P, _P, _P] + [c_int] * 4 + [_P, _P, _P], c_int),

@@ -700,20 +700,28 @@ def stem_conv_bn_relu_maxpool(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm
     assert stem_ok(conv, bn, x)
     n, _, h, w = x.shape
     store = conv.__dict__.setdefault("_ndet_packed", {})
-    stamp = (conv.weight.data_ptr(), conv.weight._version)
+    f16 = ARITHMETIC == "f16x2"          # fp16-pair form: three products per multiply, the patch scaled by its own maximum inside the kernel
+    stamp = (conv.weight.data_ptr(), conv.weight._version, f16)
     hit = store.get("stem")
     lib = _lib.load()
     st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     if hit is None or hit[0] != stamp:
-        planes = torch.empty((3, 64, 176), dtype=torch.int16, device=x.device)
-        check(lib.ndet_stem_pack_weights(_ptr(conv.weight.detach().float().contiguous()), _ptr(planes), st), "stem_pack_weights")
-        hit = store["stem"] = (stamp, planes)
+        wf = conv.weight.detach().float().contiguous()
+        if f16:
+            wscale = f16_weight_scale(float(wf.abs().max()))
+            planes = torch.empty((2, 64, 176), dtype=torch.int16, device=x.device)
+            check(lib.ndet_stem_pack_weights_f16x2(_ptr(wf), wscale, _ptr(planes), st), "stem_pack_weights_f16x2")
+            hit = store["stem"] = (stamp, planes, 1.0 / wscale)
+        else:
+            planes = torch.empty((3, 64, 176), dtype=torch.int16, device=x.device)
+            check(lib.ndet_stem_pack_weights(_ptr(wf), _ptr(planes), st), "stem_pack_weights")
+            hit = store["stem"] = (stamp, planes, 0.0)
     scale, shift = bn_affine(bn)
     ch, cw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     out = torch.empty((n, (ch - 1) // 2 + 1, (cw - 1) // 2 + 1, 64), dtype=torch.float32, device=x.device)
     sn, sc, sy, sx = x.stride()
     out_amax = AMAX.take(x.device) if (ARITHMETIC == "f16x2" and not NO_AMAX_COMMIT) else None       # the first bottleneck's activation scale
-    trace.span("k_stem_conv_pool", lambda: check(lib.ndet_stem_conv_bn_relu_maxpool(_ptr(x), n, h, w, sn, sc, sy, sx, _ptr(hit[1]), _ptr(scale), _ptr(shift),
+    trace.span("k_stem_conv_pool", lambda: check(lib.ndet_stem_conv_bn_relu_maxpool(_ptr(x), n, h, w, sn, sc, sy, sx, _ptr(hit[1]), hit[2], _ptr(scale), _ptr(shift),
                                                                                   _ptr(out), _ptr(out_amax), st), "stem_conv_bn_relu_maxpool"),
                flops=2 * n * ch * cw * 64 * 147, bytes=4 * (x.numel() + out.numel()), kind="stem")
     if out_amax is not None:

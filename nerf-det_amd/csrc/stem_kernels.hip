@@ -42,6 +42,7 @@ struct StemParams {
     const float* shift;
     float* out;            // (N, PH, PW, 64)
     float* amax_out;       // max |out| slot (conv_common.hpp) or null
+    float winv;            // fp16-pair form: 1 / (the weight planes' power-of-two scale)
 };
 
 __device__ __forceinline__ uint32_t st_pack(float x, float y) {
@@ -49,19 +50,26 @@ __device__ __forceinline__ uint32_t st_pack(float x, float y) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// SCH 0: three bf16 planes per operand, six products (exact operands).  SCH 1: two fp16 planes, three products (conv_split_kernels.hip's fp16-pair
+// scheme): the weights pre-scaled once, the patch by the power of two of ITS OWN maximum (the patch is split, multiplied and discarded inside this
+// workgroup: a tile-local scale is legal and needs neither an amax slot of the images nor a range guard); half the matrix work -- the kernel spends
+// 5.5 of its 8.2 us per tile multiplying (s_memtime stamps), two workgroups per CU sharing the matrix pipes.
+template <int SCH>
 __global__ __launch_bounds__(256, 2) void k_stem_conv_pool(const StemParams p) {
-    __shared__ __attribute__((aligned(16))) uint16_t P[3 * 3 * ST_IY * ST_PITCH];   // [plane][c][iy][pitch]
+    constexpr int NPL = SCH == 1 ? 2 : 3;
+    __shared__ __attribute__((aligned(16))) uint16_t P[NPL * 3 * ST_IY * ST_PITCH];   // [plane][c][iy][pitch]
     __shared__ __attribute__((aligned(16))) float Cs[128 * ST_CLD];
+    __shared__ float s_pmax[4];
     constexpr int PPL = 3 * ST_IY * ST_PITCH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    for (int i = tid; i < 3 * PPL; i += 256) P[i] = 0;          // the pad column must be a finite zero
+    for (int i = tid; i < NPL * PPL; i += 256) P[i] = 0;        // the pad column must be a finite zero
     // ---- weight fragments of this wave's 32 output channels: registers for the whole launch ----
     const int frow = lane & 31, fh = lane >> 5;
-    bf16x8 fb[3][ST_KS];
+    bf16x8 fb[NPL][ST_KS];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
         for (int ks = 0; ks < ST_KS; ++ks)
             fb[pl][ks] = *reinterpret_cast<const bf16x8*>(p.w + ((int64_t)(pl * 64 + wn * 32 + frow) * ST_K + ks * 16 + fh * 8));
@@ -103,16 +111,36 @@ __global__ __launch_bounds__(256, 2) void k_stem_conv_pool(const StemParams p) {
     int t = blockIdx.x;
     if (t < p.tiles) load_patch(t);
     for (; t < p.tiles; t += gridDim.x) {
-        // ---- patch -> three bf16 planes in LDS ----
+        // ---- patch -> operand planes in LDS ----
+        float xs = 1.0f, xinv = 1.0f;
+        if constexpr (SCH == 1) {                                        // the patch's own maximum -> its power-of-two scale
+            float m = 0.0f;
+#pragma unroll
+            for (int i = 0; i < ST_EPT; ++i) m = fmaxf(m, fabsf(ra[i]));
+#pragma unroll
+            for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if (lane == 0) s_pmax[wave] = m;
+            __syncthreads();                                             // (also: the previous tile's MFMA reads of P are done -- all waves passed (B))
+            m = fmaxf(fmaxf(s_pmax[0], s_pmax[1]), fmaxf(s_pmax[2], s_pmax[3]));
+            xs = conv_xscale_of(m);
+            xinv = conv_xinv_of(m) * p.winv;
+        }
 #pragma unroll
         for (int i = 0; i < ST_EPT; ++i)
             if (e_lds[i] >= 0) {
-                const float v = ra[i];
-                const uint32_t o0 = st_pack(v, 0.0f);
-                const float r1 = v - __uint_as_float(o0 << 16);
-                const uint32_t o1 = st_pack(r1, 0.0f);
-                const uint32_t o2 = st_pack(r1 - __uint_as_float(o1 << 16), 0.0f);
-                P[e_lds[i]] = (uint16_t)o0; P[PPL + e_lds[i]] = (uint16_t)o1; P[2 * PPL + e_lds[i]] = (uint16_t)o2;
+                if constexpr (SCH == 1) {
+                    const float v = ra[i] * xs;
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)(v - (float)h);
+                    P[e_lds[i]] = __builtin_bit_cast(uint16_t, h); P[PPL + e_lds[i]] = __builtin_bit_cast(uint16_t, l);
+                } else {
+                    const float v = ra[i];
+                    const uint32_t o0 = st_pack(v, 0.0f);
+                    const float r1 = v - __uint_as_float(o0 << 16);
+                    const uint32_t o1 = st_pack(r1, 0.0f);
+                    const uint32_t o2 = st_pack(r1 - __uint_as_float(o1 << 16), 0.0f);
+                    P[e_lds[i]] = (uint16_t)o0; P[PPL + e_lds[i]] = (uint16_t)o1; P[2 * PPL + e_lds[i]] = (uint16_t)o2;
+                }
             }
         __syncthreads();                                             // (A) patch complete; the previous tile's pooling has read Cs
         const int tn = t + gridDim.x;
@@ -133,22 +161,29 @@ __global__ __launch_bounds__(256, 2) void k_stem_conv_pool(const StemParams p) {
                 if (g > 20) g = 20;                                      // padding slice: zero weights, any finite operand
                 const int ky = g / 3, c = g - 3 * ky;
                 const int goff = (c * ST_IY + ky) * ST_PITCH;
-                bf16x8 fa[3];
+                bf16x8 fa[NPL];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
+                for (int pl = 0; pl < NPL; ++pl) {
                     const uint32_t* q = reinterpret_cast<const uint32_t*>(P + pl * PPL + goff + ao);   // 4-byte aligned: the offsets are even
                     const u32x4 v = {q[0], q[1], q[2], q[3]};
                     fa[pl] = __builtin_bit_cast(bf16x8, v);
                 }
+                if constexpr (SCH == 1) {                                // smallest terms first: hi lo, lo hi, hi hi
+                    typedef _Float16 st_f16x8 __attribute__((ext_vector_type(8)));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(st_f16x8, fa[0]), __builtin_bit_cast(st_f16x8, fb[1][ks]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(st_f16x8, fa[1]), __builtin_bit_cast(st_f16x8, fb[0][ks]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(st_f16x8, fa[0]), __builtin_bit_cast(st_f16x8, fb[0][ks]), acc, 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int order = 2; order >= 0; --order)
+                    for (int order = 2; order >= 0; --order)
 #pragma unroll
-                    for (int pa = 0; pa <= order; ++pa) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa], fb[order - pa][ks], acc, 0, 0, 0);
+                        for (int pa = 0; pa <= order; ++pa) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa], fb[order - pa][ks], acc, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                Cs[row * ST_CLD + wn * 32 + frow] = fmaxf(acc[r] * sc + sh, 0.0f);
+                Cs[row * ST_CLD + wn * 32 + frow] = fmaxf((SCH == 1 ? acc[r] * xinv : acc[r]) * sc + sh, 0.0f);
             }
         }
         __syncthreads();                                             // (B)
@@ -199,6 +234,30 @@ __global__ __launch_bounds__(256) void k_stem_pack_weights(const float* __restri
     out[i] = (uint16_t)o0; out[64 * ST_K + i] = (uint16_t)o1; out[2 * 64 * ST_K + i] = (uint16_t)o2;
 }
 
+// the fp16-pair form: (2 planes, 64, 176) fp16 of w * scale (scale: a power of two putting max |w| in [2^14, 2^15), chosen by the caller)
+__global__ __launch_bounds__(256) void k_stem_pack_weights_f16x2(const float* __restrict__ w, float scale, uint16_t* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 64 * ST_K) return;
+    const int co = i / ST_K, k = i - co * ST_K;
+    const int g = k >> 3, kx = k & 7;
+    float v = 0.0f;
+    if (g < 21 && kx < 7) {
+        const int ky = g / 3, c = g - 3 * ky;
+        v = w[((co * 3 + c) * 7 + ky) * 7 + kx] * scale;
+    }
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    out[i] = __builtin_bit_cast(uint16_t, h); out[64 * ST_K + i] = __builtin_bit_cast(uint16_t, l);
+}
+
+extern "C" int ndet_stem_pack_weights_f16x2(const float* w_64x3x7x7, float scale, uint16_t* planes, void* stream) {
+    const char* fn = "ndet_stem_pack_weights_f16x2";
+    NDET_REQUIRE(w_64x3x7x7 && planes && scale > 0.0f, NDET_E_INVALID, "%s: null pointer / non-positive scale", fn);
+    hipLaunchKernelGGL(k_stem_pack_weights_f16x2, dim3((64 * ST_K + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_64x3x7x7, scale, planes);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
+
 extern "C" int ndet_stem_pack_weights(const float* w_64x3x7x7, uint16_t* planes, void* stream) {
     const char* fn = "ndet_stem_pack_weights";
     NDET_REQUIRE(w_64x3x7x7 && planes, NDET_E_INVALID, "%s: null pointer", fn);
@@ -208,8 +267,8 @@ extern "C" int ndet_stem_pack_weights(const float* w_64x3x7x7, uint16_t* planes,
 }
 
 extern "C" int ndet_stem_conv_bn_relu_maxpool(const float* images, int N, int H, int W, int64_t stride_n, int64_t stride_c, int64_t stride_y,
-                                              int64_t stride_x, const uint16_t* w_planes, const float* scale, const float* shift, float* out,
-                                              float* out_amax, void* stream) {
+                                              int64_t stride_x, const uint16_t* w_planes, float w_inv_scale, const float* scale, const float* shift,
+                                              float* out, float* out_amax, void* stream) {
     const char* fn = "ndet_stem_conv_bn_relu_maxpool";
     NDET_REQUIRE(images && w_planes && scale && shift && out, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(N > 0 && H >= 7 && W >= 7, NDET_E_INVALID, "%s: bad sizes", fn);
@@ -223,9 +282,11 @@ extern "C" int ndet_stem_conv_bn_relu_maxpool(const float* images, int N, int H,
     const int64_t tiles = (int64_t)N * p.tiles_y * p.tiles_x;
     NDET_REQUIRE(tiles < ((int64_t)1 << 31), NDET_E_UNSUPPORTED, "%s: too many tiles", fn);
     p.tiles = (int)tiles;
-    p.w = w_planes; p.scale = scale; p.shift = shift; p.out = out; p.amax_out = out_amax;
+    NDET_REQUIRE(w_inv_scale >= 0.0f, NDET_E_INVALID, "%s: w_inv_scale is 0 (bf16x3 planes) or the fp16-pair planes' inverse scale", fn);
+    p.w = w_planes; p.scale = scale; p.shift = shift; p.out = out; p.amax_out = out_amax; p.winv = w_inv_scale;
     const int grid = (int)(tiles < 512 ? tiles : 512);               // two persistent workgroups per CU
-    hipLaunchKernelGGL(k_stem_conv_pool, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    if (w_inv_scale > 0.0f) hipLaunchKernelGGL(k_stem_conv_pool<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(k_stem_conv_pool<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
