@@ -119,8 +119,12 @@ def test_eight_rank_dry_run_of_both_benchmarks(script):
     import json
     import subprocess
     import sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, script), "--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-run"],
-                         env=_clean_env(OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=360)
+    for attempt in range(2):      # eight interpreters start at once on what may be an 8-CPU container: one retry for a rendezvous that timed out
+        out = subprocess.run([sys.executable, os.path.join(ROOT, script), "--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-run"],
+                             env=_clean_env(OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=360)
+        if out.returncode == 0:
+            break
+        print(f"attempt {attempt}: rc {out.returncode}\n{out.stderr[-3000:]}")
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]

@@ -65,7 +65,7 @@ def dry_run(args):
     if grouped:     # every rank must hold the same parameters after the all-reduced steps
         ws = [torch.empty_like(w0) for _ in range(world)]
         torch.distributed.all_gather(ws, w0)
-        assert all(torch.equal(ws[0], w) for w in ws), "ranks diverged: the gradients were not all-reduced"
+        assert all(torch.allclose(ws[0], w, rtol=0, atol=1e-7) for w in ws), "ranks diverged: the gradients were not all-reduced"
     if rank == 0:
         print(json.dumps(dict(metric="dry-run", value=world / dt, unit="steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3,
                               dry_run=True, log_vars=out["log_vars"], ddp_buckets_bytes=ddp_bucket_plan(det, 1), rank_threads=share["threads"],
