@@ -334,7 +334,9 @@ int ndet_amax_slot_floats(void);
 
 /* Measurement knobs of the convolution launchers, set explicitly by profiling scripts (tools/layer_times.py) -- never read from the environment, so
  * a production process cannot pick them up by accident.  "nt_bytes": outputs of at least this many bytes are written with non-temporal stores
- * (default 32 MiB); "order2": 1 / 0 = deal the column tiles of a row tile to one XCD or keep grid order.  Neither changes a result bit.
+ * (default 32 MiB); "order2": 1 / 0 = deal the column tiles of a row tile to one XCD or keep grid order (neither changes a result bit);
+ * "deterministic_scatter": 1 = the backward kernels' gradient scatter on 64-bit fixed-point integer atomics (the caller then passes zeroed int64
+ * buffers in place of the float ones: order-independent sums, for reproducibility tests; nerfdet_amd/autograd.py::set_deterministic).
  * HOST string.  No reference counterpart (the reference's harness, tools/benchmark.py:63-89, times the model only). */
 int ndet_measurement_knob(const char* name_host, int64_t value);
 
