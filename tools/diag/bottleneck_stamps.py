@@ -1,3 +1,6 @@
+"""GPU box: per-phase clock stamps of the whole-bottleneck kernel.  Needs a library whose bottleneck_kernels.hip was compiled with -DBT_STAMPS
+(hipcc ... -DBT_STAMPS -c bottleneck_kernels.hip, linked with the other objects as the Makefile does) in place of nerf-det_amd/lib/libnerfdet_hip.so.
+HISTORY.md R4.3 holds the numbers this produced."""
 import os, sys, ctypes, torch
 sys.path.insert(0, "/root/repo")
 from nerfdet_amd import conv3d as C, _lib

@@ -1,4 +1,6 @@
-"""GPU box, diagnostic build of the stem kernel with clock stamps (see HISTORY R4): where a tile's time goes."""
+"""GPU box: where a tile of the stem kernel spends its time.  Needs a diagnostic build of stem_kernels.hip that accumulates wall_clock64() differences
+per workgroup and exports ndet_st_set_stamps (the stamps were a throw-away patch of round 4: split + store 0.6 us, multiply + stage 5.5 us, pool +
+store 2.1 us per tile in the bf16x3 form; HISTORY.md R4).  Kept as the reader of that buffer."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nerfdet_amd import conv3d as C, _lib
