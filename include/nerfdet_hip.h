@@ -463,12 +463,50 @@ int ndet_wgrad_split(const float* x_ndhwc, int D, int H, int W, int Cin, const i
  * nn.Conv2d in mmdet3d/models/necks/imvoxelnet.py:22-67,233-260 and of the ResNet / FPN layers. */
 int ndet_wgrad_dy_planes(const float* dy_rows_by_voxel, int L, int Cout, int lrow, uint16_t* planes, void* stream);
 
+/* fp16-pair forms of the two calls above (the training step on the three-product arithmetic): dy's planes are (lrow/32, 2, Cout, 32), two fp16
+ * halves of dy * 2^k with 2^k taken ON THE DEVICE from dy's amax slot (ndet_amax_f32; largest magnitude in [2^14, 2^15)); ndet_wgrad_split_f16x2
+ * splits x the same way under x_amax and multiplies the sums by the inverse of both scales, read from the same slots.  Same reference as
+ * ndet_wgrad_split: autograd of nn.Conv3d / nn.Conv2d in mmdet3d/models/necks/imvoxelnet.py:22-67,233-260 and of the ResNet / FPN layers. */
+int ndet_wgrad_dy_planes_f16x2(const float* dy_rows_by_voxel, int L, int Cout, int lrow, const float* dy_amax, uint16_t* planes, void* stream);
+int ndet_wgrad_split_f16x2(const float* x_ndhwc, int D, int H, int W, int Cin, const int* kernel, const int* stride, const int* pad,
+                           const uint16_t* dy_planes, int Cout, int lrow, int splits, const float* x_amax, const float* dy_amax, void* workspace,
+                           float* dw_rows, void* stream);
+
+/* Both weight packs of one training step in ONE pass over a torch-layout weight (Cout, Cin, taps <= 27): planes = the layer's own
+ * (taps, Cin/32, P, Cout, 32), planes_adjoint (may be null) = its data gradient's (taps, ceil32(Cout)/32, P, Cin, 32), W'[t][ci][co] = W[co][ci][taps-1-t]
+ * (see ndet_split_weights_bf16x3_torch).  arith 0: P = 3 bf16 planes (w_amax null).  arith 1: P = 2 fp16 planes of w * 2^k, 2^k derived on the
+ * device from the weight's amax slot w_amax (ndet_amax_f32) -- the optimizer moves the weights every step
+ * (config nerfdet_res50_2x_low_res.py:167-172, AdamW), and no maximum has to reach the host for it.  A workgroup moves a 32 x 32 (co, ci) block with
+ * all its taps through LDS: coalesced reads of the torch layout, every (tap, plane) of either pack written as one 2 KB piece. */
+int ndet_split_weights_train(const float* w_torch, int taps, int Cout, int Cin, int arith, const float* w_amax, uint16_t* planes,
+                             uint16_t* planes_adjoint, void* stream);
+
+/* The weight gradient in torch's layout: dw_rows ((tap, ci) rows x Cout floats, what ndet_wgrad_split* and the staged GEMM write) ->
+ * dw_torch (Cout, Cin, taps), the layout autograd hands to the optimizer for nn.Conv3d / nn.Conv2d.weight
+ * (mmdet3d/models/necks/imvoxelnet.py:22-67,233-260).  32 x 32 x taps blocks through LDS, coalesced on both sides; taps <= 27, Cin % 32 == 0. */
+int ndet_wgrad_to_torch(const float* dw_rows, int taps, int Cout, int Cin, float* dw_torch, void* stream);
+
+/* The fp16-pair convolution launch of the training step (forward and data gradient of the convolutions of
+ * mmdet3d/models/necks/imvoxelnet.py:22-67,233-260, dense_heads/imvoxel_head_v2.py:45-58,444-449 and the trainable ResNet / FPN layers behind
+ * detectors/nerfdet.py:140-142): ndet_conv_ndhwc_guarded with arith = 1 whose weight planes were scaled on the device -- by ndet_split_weights_train,
+ * or, for the weight-gradient GEMM over ndet_wgrad_rows' tap copies, dy's planes from ndet_wgrad_dy_planes_f16x2 -- so 1 / (weight scale) is taken
+ * from the slot w_amax instead of a host float.  guard (may be null): the range guard with ||w||_1 bounded by guard_k * max|w|, guard_k = taps * Cin. */
+int ndet_conv_ndhwc_train(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout, const int* kernel,
+                          const int* stride, const int* pad, const float* scale, const float* shift, const float* residual, int relu, int splits,
+                          int tile, const float* in_amax, const float* w_amax, float* out_amax, void* workspace, float guard_k, float guard_tol,
+                          unsigned* guard, void* stream);
+
 /* Backward of the fused epilogue y = relu(conv * scale + shift (+ identity)) -- convolution + frozen eval-mode BatchNorm + ReLU (+ the
  * bottleneck's identity) of the trainable ResNet stages (mmdet Bottleneck.forward behind mmdet3d/models/detectors/nerfdet.py:140;
  * config: norm_eval=True, norm_cfg.requires_grad=False): d_identity = dy [y > 0] (null = not wanted), d_conv = d_identity * scale[c],
  * one pass over `rows` channels-last rows of C floats (C % 4 == 0).  relu = 0: no mask (y may be null). */
 int ndet_relu_affine_bwd(const float* dy, const float* y, const float* scale, int64_t rows, int C, int relu, float* d_identity,
                          float* d_conv, void* stream);
+/* ndet_relu_affine_bwd that also leaves max |d_conv| in the zeroed 1 KiB amax slot d_conv_amax (see ndet_amax_f32): d_conv is the operand of the
+ * layer's data and weight gradients, whose fp16-pair launches take their scale from that slot.  Same reference: mmdet Bottleneck.forward behind
+ * mmdet3d/models/detectors/nerfdet.py:140 under norm_eval=True. */
+int ndet_relu_affine_bwd_amax(const float* dy, const float* y, const float* scale, int64_t rows, int C, int relu, float* d_identity,
+                              float* d_conv, float* d_conv_amax, void* stream);
 
 /* ---- backward passes (training).  The reference obtains these from autograd over its materialised tensors; each
  * entry point names the forward statement it differentiates.  Scatter targets must be zero-initialised by the caller;

@@ -81,7 +81,13 @@ SIGNATURES = {
     "ndet_stem_conv_bn_relu_maxpool": ([_P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, _P, c_float, _P, _P, _P, _P, _P], c_int),
     "ndet_stem_pack_weights_f16x2": ([_P, c_float, _P, _P], c_int),
     "ndet_wgrad_dy_planes": ([_P, c_int, c_int, c_int, _P, _P], c_int),
+    "ndet_wgrad_dy_planes_f16x2": ([_P, c_int, c_int, c_int, _P, _P, _P], c_int),
+    "ndet_wgrad_split_f16x2": ([_P] + [c_int] * 4 + [_P, _P, _P, _P] + [c_int] * 3 + [_P, _P, _P, _P, _P], c_int),
+    "ndet_wgrad_to_torch": ([_P, c_int, c_int, c_int, _P, _P], c_int),
+    "ndet_split_weights_train": ([_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P], c_int),
+    "ndet_conv_ndhwc_train": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P], c_int),
     "ndet_relu_affine_bwd": ([_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P], c_int),
+    "ndet_relu_affine_bwd_amax": ([_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P], c_int),
     "ndet_wgrad_split": ([_P] + [c_int] * 4 + [_P, _P, _P, _P] + [c_int] * 4 + [_P, _P, _P], c_int),
     "ndet_wgrad_rows": ([_P] + [c_int] * 4 + [_P, _P, _P] + [c_int] * 3 + [_P, _P], c_int),
     "ndet_bn_relu_maxpool_nhwc": ([_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P], c_int),

@@ -42,9 +42,16 @@ def set_arithmetic(mode: str) -> str:
     return prev
 
 
+TRAIN_F16X2 = True     # the training step's convolutions (forward, data and weight gradients: conv_train.py) on the fp16-pair arithmetic as well, every
+                       # scale taken on the device from an amax slot (weights: one ndet_amax_f32 per tensor and step; dy: per gradient tensor).  False: the
+                       # six-product bf16x3 kernels (exact operands; what the deterministic-trajectory tests of rounds 3-4 were pinned on)
+
+
 def train_arithmetic() -> str:
-    """What the training kernels (data / weight gradients, nerfdet_amd/conv_train.py) compute in under the current mode."""
-    return "bf16x3" if ARITHMETIC == "f16x2" else ARITHMETIC
+    """What the training kernels (forward under autograd, data / weight gradients: nerfdet_amd/conv_train.py) compute in under the current mode."""
+    if ARITHMETIC == "f16x2":
+        return "f16x2" if TRAIN_F16X2 else "bf16x3"
+    return ARITHMETIC
 
 
 class _AmaxSlots:
@@ -66,6 +73,16 @@ class _AmaxSlots:
         slot = pool[0][pool[1]:pool[1] + self.WIDTH]
         pool[1] += self.WIDTH
         return slot
+
+    def take_many(self, device, n: int) -> torch.Tensor:
+        """``n`` consecutive zeroed slots as one (n, WIDTH) tensor (row i is a slot)."""
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        pool = self.pools.get(key)
+        if pool is None or pool[1] + n * self.WIDTH > pool[0].numel():
+            pool = self.pools[key] = [torch.zeros(max(4096, n) * self.WIDTH, dtype=torch.float32, device=device), 0]
+        block = pool[0][pool[1]:pool[1] + n * self.WIDTH].view(n, self.WIDTH)
+        pool[1] += n * self.WIDTH
+        return block
 
     def fresh(self, device):
         """Drop the current stream's pool: the next slot comes from a new zero fill (graph capture: the fill must be part of the graph)."""
@@ -365,7 +382,7 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
     arith = layer_arithmetic(k_iters)
     if ARITHMETIC == "f16x2" and pk.get("arith"):
         arith = pk["arith"]            # pinned packs: training (conv_train.py: the weights change every step) and the point MLPs (packed_linear)
-        want_amax = False              # (a reader in the fp16-pair arithmetic takes its own pass, amax_of)
+        want_amax = want_amax and bool(pk.get("keep_amax"))    # (otherwise a reader in the fp16-pair arithmetic takes its own pass, amax_of)
     if NO_AMAX_COMMIT:
         want_amax = False
     if ARITHMETIC != "f16x2":
@@ -376,6 +393,20 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
                                      "conv_ndhwc_split"), arith, tile, nbytes)
         return out
     # fp16-pair mode: every launch leaves max |out| behind; the fp16-pair launches read their input's
+    if arith == "f16x2" and pk.get("w_amax") is not None:
+        # training packs (conv_train.py): planes scaled on the device by the slot pk["w_amax"]; plain convolutions only
+        assert not transposed and not residual_up2
+        planes, in_amax = pk["w_f16"][0], amax_of(x)
+        out_amax = AMAX.take(x.device) if want_amax else None
+        gw = guard_word(x.device) if pk.get("guard", True) else None
+        _launch(flops, lambda: check(lib.ndet_conv_ndhwc_train(_ptr(x), _ptr(planes), _ptr(out), d, h, w, pk["cin"], pk["cout"], i3(kernel), i3(stride), i3(pad),
+                                                               _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), relu, splits, tile, _ptr(in_amax),
+                                                               _ptr(pk["w_amax"]), _ptr(out_amax), _ptr(ws), float(kernel[0] * kernel[1] * kernel[2] * pk["cin"]),
+                                                               GUARD_TOL, _ptr(gw), st),
+                                     "conv_ndhwc_train"), arith, tile, nbytes)
+        if want_amax:
+            _tag_amax(out, out_amax)
+        return out
     if arith == "f16x2":
         planes, winv = split_planes_f16(pk)
         in_amax = amax_of(x)

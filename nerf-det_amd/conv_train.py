@@ -35,21 +35,91 @@ def _raw_pack(w_taps_co_ci: Tensor, kernel: Sequence[int], stride: int = 1, pads
                 pads=tuple(v // 2 for v in k) if pads is None else tuple(pads), ndim=ndim, arith="bf16x3")
 
 
-def _train_pack(w: Tensor, kernel, adjoint: bool, stride: int = 1, pads=None) -> dict:
-    """Pack dict for the layer (or, ``adjoint``, for its data gradient) straight from the torch-layout weight: with the bf16x3
-    kernels one launch writes the three bf16 planes (ndet_split_weights_bf16x3_torch); the fp32-MFMA family goes through the
-    generic packer."""
+_STEP_SLOTS = {}      # (weight address, version) -> amax slot, filled by prepare_step for ONE step (cleared by the next call)
+_STEP_PARAMS = {}     # id(module) -> its trainable convolution weights on the GPU
+
+
+def prepare_step(module: nn.Module) -> int:
+    """Before a training step's forward (train.train_one_step): max |w| of every trainable convolution weight into an amax slot with two launches
+    for the whole model (``torch._foreach_norm`` + one strided copy) instead of one ndet_amax_f32 per tensor -- 65 launches per step in the shipped
+    model.  Weights it did not see fall back to their own pass (:func:`_split_both`).  Returns the number of slots prepared."""
+    _STEP_SLOTS.clear()
+    if C.train_arithmetic() != "f16x2":
+        return 0
+    ws = _STEP_PARAMS.get(id(module))
+    if ws is None:
+        ws = _STEP_PARAMS[id(module)] = [m.weight for m in module.modules() if isinstance(m, (nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d))
+                                         and m.weight.requires_grad and m.weight.is_cuda and m.weight.dtype == torch.float32]
+    if not ws:
+        return 0
+    with torch.no_grad():
+        norms = torch._foreach_norm([w.detach() for w in ws], float("inf"))
+        block = C.AMAX.take_many(ws[0].device, len(ws))
+        block[:, 0] = torch.stack(norms)
+    for i, w in enumerate(ws):
+        _STEP_SLOTS[(w.data_ptr(), w._version)] = block[i]
+    return len(ws)
+
+
+def _split_both(w: Tensor, taps: int, arith: str, want_adjoint: bool):
+    """(planes, adjoint planes or None, amax slot or None) of the torch-layout weight ``w``: ONE launch writes both packs
+    (ndet_split_weights_train); the forward hands the adjoint planes to its backward through the autograd context, so a step splits each weight
+    once.  fp16-pair: the scale comes from the weight's amax slot (one ndet_amax_f32 launch); nothing is read back to the host."""
+    from ctypes import c_void_p
+    from . import _lib
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    npl = 2 if arith == "f16x2" else 3
+    planes = torch.empty((taps, cin // 32, npl, cout, 32), dtype=torch.int16, device=w.device)
+    adj = torch.empty((taps, (cout + 31) // 32, npl, cin, 32), dtype=torch.int16, device=w.device) if want_adjoint else None
+    wc = w.contiguous()
+    st = c_void_p(torch.cuda.current_stream(w.device).cuda_stream)
+    slot = None
+    if arith == "f16x2":
+        slot = _STEP_SLOTS.get((w.data_ptr(), w._version))
+        if slot is None:
+            slot = C.AMAX.take(w.device)
+            _lib.check(_lib.load().ndet_amax_f32(c_void_p(wc.data_ptr()), wc.numel(), c_void_p(slot.data_ptr()), st), "amax_f32")
+    _lib.check(_lib.load().ndet_split_weights_train(c_void_p(wc.data_ptr()), taps, cout, cin, 1 if arith == "f16x2" else 0, c_void_p(0 if slot is None else slot.data_ptr()),
+                                                    c_void_p(planes.data_ptr()), c_void_p(0 if adj is None else adj.data_ptr()), st), "split_weights_train")
+    return planes, adj, slot
+
+
+def _plane_pack(w: Tensor, planes: Tensor, slot, arith: str, kernel, adjoint: bool, stride: int = 1, pads=None) -> dict:
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    no, ki = (cin, (cout + 31) // 32 * 32) if adjoint else (cout, cin)
+    k = tuple(int(v) for v in kernel)
+    pk = dict(w=w, scale=None, shift=None, cout=no, cin=ki, ksize=k[0], stride=stride, transposed=False, kernel=k,
+              strides=(stride,) * len(k), pads=tuple(v // 2 for v in k) if pads is None else tuple(pads), ndim=len(k), arith="bf16x3")
+    if arith == "f16x2":
+        pk.update(arith="f16x2", w_f16=(planes, 1.0), w_amax=slot, keep_amax=True)
+    else:
+        pk["w_split"] = planes
+    return pk
+
+
+def _train_pack(w: Tensor, kernel, adjoint: bool, stride: int = 1, pads=None, want_adjoint: bool = False) -> dict:
+    """Pack dict for the layer (or, ``adjoint``, for its data gradient) straight from the torch-layout weight.  Split-family kernels: one launch
+    writes the layer's planes and -- ``want_adjoint`` -- its data gradient's, returned under ``"_adjoint"`` for :func:`_adjoint_pack`; the
+    fp32-MFMA family goes through the generic packer."""
     cout, cin = int(w.shape[0]), int(w.shape[1])
     taps = 1
     for v in kernel:
         taps *= int(v)
-    if C.train_arithmetic() not in ("bf16x3", "bf16"):
+    arith = C.train_arithmetic()
+    if arith not in ("bf16x3", "bf16", "f16x2"):
         if not adjoint:
             return _raw_pack(C.pack_weight(w), kernel, stride, pads)
         flip = w.flip(tuple(range(2, w.dim()))).transpose(0, 1)
         if cout % 32:
             flip = torch.nn.functional.pad(flip, (0, 0) * (w.dim() - 2) + (0, 32 - cout % 32))
         return _raw_pack(C.pack_weight(flip), kernel)
+    if taps <= 27:
+        planes, adj, slot = _split_both(w, taps, arith, adjoint or want_adjoint)
+        pk = _plane_pack(w, adj if adjoint else planes, slot, arith, kernel, adjoint, stride, pads)
+        if want_adjoint and not adjoint:
+            pk["_adjoint"] = (adj, slot, arith)
+        return pk
+    # more taps than one workgroup's LDS block takes (none among the shipped models' trainable layers): one pack per launch, six-product arithmetic
     from ctypes import c_void_p
     from . import _lib
     no, ki = (cin, (cout + 31) // 32 * 32) if adjoint else (cout, cin)
@@ -57,9 +127,14 @@ def _train_pack(w: Tensor, kernel, adjoint: bool, stride: int = 1, pads=None) ->
     wc = w.contiguous()
     _lib.check(_lib.load().ndet_split_weights_bf16x3_torch(c_void_p(wc.data_ptr()), taps, cout, cin, int(adjoint), c_void_p(planes.data_ptr()),
                                                            c_void_p(torch.cuda.current_stream(w.device).cuda_stream)), "split_weights_torch")
-    k = tuple(int(v) for v in kernel)
-    return dict(w=wc, w_split=planes, scale=None, shift=None, cout=no, cin=ki, ksize=k[0], stride=stride, transposed=False, kernel=k,
-                strides=(stride,) * len(k), pads=tuple(v // 2 for v in k) if pads is None else tuple(pads), ndim=len(k), arith="bf16x3")
+    return _plane_pack(w, planes, None, "bf16x3", kernel, adjoint, stride, pads)
+
+
+def _adjoint_pack(handed, w: Tensor, kernel) -> dict:
+    """The data gradient's pack: the planes the forward wrote alongside its own (``handed`` = its ``"_adjoint"`` entry), or a fresh split."""
+    if handed is not None and handed[2] == C.train_arithmetic():
+        return _plane_pack(w, handed[0], handed[1], handed[2], kernel, True)
+    return _train_pack(w, kernel, True)
 
 
 def _conv(x: Tensor, pk: dict) -> Tensor:
@@ -97,6 +172,18 @@ def _rows(x: Tensor, k3, stride3, pads, t0: int, n_taps: int, lrow: int) -> Tens
     return out
 
 
+def _to_torch_layout(dw_rows: Tensor, taps: int, cin: int, cout: int, kernel) -> Tensor:
+    """(taps * Cin, Cout) GEMM rows -> (Cout, Cin, *kernel): one coalesced pass (csrc: k_wgrad_to_torch) instead of ATen's strided copy."""
+    if taps > 27 or cin % 32:
+        return dw_rows.view(taps, cin, cout).permute(2, 1, 0).reshape(cout, cin, *kernel)
+    from ctypes import c_void_p
+    from . import _lib
+    out = torch.empty((cout, cin) + tuple(kernel), dtype=torch.float32, device=dw_rows.device)
+    _lib.check(_lib.load().ndet_wgrad_to_torch(c_void_p(dw_rows.data_ptr()), taps, cout, cin, c_void_p(out.data_ptr()),
+                                               c_void_p(torch.cuda.current_stream(dw_rows.device).cuda_stream)), "wgrad_to_torch")
+    return out
+
+
 def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pads=None, implicit=None) -> Tensor:
     """dW of a convolution of uniform stride (same-padded unless ``pads`` says otherwise).  x (D,H,W,Cin), g (OD,OH,OW,Cout) contiguous fp32
     channels-last (2D: D = batch, kernel (kh,kw)) -> (Cout, Cin, *kernel) in torch's layout."""
@@ -110,29 +197,42 @@ def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pa
     lo = g.shape[0] * g.shape[1] * g.shape[2]
     lrow = ((lo + 31) // 32) * 32                           # the kernel steps the contraction by 32; the tail is staged as zeros
     taps = k3[0] * k3[1] * k3[2]
-    # dy as the GEMM's "weight" operand (Cout rows over the output grid), split into bf16 planes once
-    if FUSED_DY_PLANES and C.train_arithmetic() in ("bf16x3", "bf16"):
+    # dy as the GEMM's "weight" operand (Cout rows over the output grid), split into its planes once
+    arith = C.train_arithmetic()
+    f16 = arith == "f16x2"
+    x_slot = dy_slot = None
+    if f16:
+        dy_slot, x_slot = C.amax_of(g), C.amax_of(x)          # device slots; the scales and their inverses never leave the device
+    if FUSED_DY_PLANES and arith in ("bf16x3", "bf16", "f16x2"):
         from ctypes import c_void_p
         from . import _lib
-        planes = torch.empty((1, lrow // 32, 3, cout, 32), dtype=torch.int16, device=x.device)     # one pass: transpose + split
-        _lib.check(_lib.load().ndet_wgrad_dy_planes(c_void_p(g.data_ptr()), lo, cout, lrow, c_void_p(planes.data_ptr()),
-                                                    c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "wgrad_dy_planes")
-        pk = dict(w=planes, w_split=planes, scale=None, shift=None, cout=cout, cin=lrow, ksize=1, stride=1, transposed=False, kernel=(1, 1),
-                  strides=(1, 1), pads=(0, 0), ndim=2, arith="bf16x3")
+        st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        planes = torch.empty((1, lrow // 32, 2 if f16 else 3, cout, 32), dtype=torch.int16, device=x.device)     # one pass: transpose + split
+        if f16:
+            _lib.check(_lib.load().ndet_wgrad_dy_planes_f16x2(c_void_p(g.data_ptr()), lo, cout, lrow, c_void_p(dy_slot.data_ptr()), c_void_p(planes.data_ptr()), st),
+                       "wgrad_dy_planes_f16x2")
+            # (no range guard: its bound, 2^-39 max|x| L max|dy|, is an absolute floor on a SUM over L output voxels -- for a weight gradient
+            # the error that matters is relative to that sum's own size, and the bound trips on every early layer)
+            pk = dict(w=planes, w_f16=(planes, 1.0), w_amax=dy_slot, guard=False, scale=None, shift=None, cout=cout, cin=lrow, ksize=1, stride=1, transposed=False,
+                      kernel=(1, 1), strides=(1, 1), pads=(0, 0), ndim=2, arith="f16x2")
+        else:
+            _lib.check(_lib.load().ndet_wgrad_dy_planes(c_void_p(g.data_ptr()), lo, cout, lrow, c_void_p(planes.data_ptr()), st), "wgrad_dy_planes")
+            pk = dict(w=planes, w_split=planes, scale=None, shift=None, cout=cout, cin=lrow, ksize=1, stride=1, transposed=False, kernel=(1, 1),
+                      strides=(1, 1), pads=(0, 0), ndim=2, arith="bf16x3")
     else:
         grows = _rows(g, (1, 1, 1), (1, 1, 1), (0, 0, 0), 0, 1, lrow)
         pk = dict(w=grows, scale=None, shift=None, cout=cout, cin=lrow, ksize=1, stride=1, transposed=False, kernel=(1, 1), strides=(1, 1),
                   pads=(0, 0), ndim=2, arith="bf16x3")
     if implicit is None:
         implicit = IMPLICIT_WGRAD and taps >= 9 and lo >= 16384
-    if implicit and C.train_arithmetic() in ("bf16x3", "bf16") and cin % 64 == 0:
+    if implicit and arith in ("bf16x3", "bf16", "f16x2") and cin % 64 == 0:
         # multi-tap layers on large grids: x read in place (csrc/conv_split_kernels.hip::k_wgrad_split), no tap copies -- there the staged
         # form writes and re-reads taps x the input (707 MB for a 3x3x3 layer at 40x40x16x256); on small grids and 1x1 layers the staged
         # GEMM runs on the faster tiles and wins (tools/bench_wgrad.py)
         import ctypes
         from ctypes import c_void_p
         from . import _lib
-        planes = C.split_planes(pk)
+        planes = pk["w_f16"][0] if f16 else C.split_planes(pk)
         bm, bn = (128 if cin % 128 == 0 else 64), (128 if cout > 64 else 64)
         tiles = (taps * cin // bm) * ((cout + bn - 1) // bn)
         ksteps = lrow // 32
@@ -142,17 +242,24 @@ def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pa
         dw = torch.empty((m, cout), dtype=torch.float32, device=x.device)
         i3 = lambda v: (ctypes.c_int * 3)(*v)
         st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        _lib.check(_lib.load().ndet_wgrad_split(c_void_p(x.data_ptr()), d, h, w, cin, i3(k3), i3(s3), i3(pads), c_void_p(planes.data_ptr()), cout, lrow,
-                                                splits, 0 if C.train_arithmetic() == "bf16" else 2, c_void_p(0 if ws is None else ws.data_ptr()),
-                                                c_void_p(dw.data_ptr()), st), "wgrad_split")
-        return dw.view(taps, cin, cout).permute(2, 1, 0).reshape(cout, cin, *kernel)
+        if f16:
+            _lib.check(_lib.load().ndet_wgrad_split_f16x2(c_void_p(x.data_ptr()), d, h, w, cin, i3(k3), i3(s3), i3(pads), c_void_p(planes.data_ptr()), cout, lrow,
+                                                          splits, c_void_p(x_slot.data_ptr()), c_void_p(dy_slot.data_ptr()), c_void_p(0 if ws is None else ws.data_ptr()),
+                                                          c_void_p(dw.data_ptr()), st), "wgrad_split_f16x2")
+        else:
+            _lib.check(_lib.load().ndet_wgrad_split(c_void_p(x.data_ptr()), d, h, w, cin, i3(k3), i3(s3), i3(pads), c_void_p(planes.data_ptr()), cout, lrow,
+                                                    splits, 0 if arith == "bf16" else 2, c_void_p(0 if ws is None else ws.data_ptr()),
+                                                    c_void_p(dw.data_ptr()), st), "wgrad_split")
+        return _to_torch_layout(dw, taps, cin, cout, kernel)
     per = max(1, min(taps, (1 << 30) // (cin * lrow * 4)))  # the kernel addresses its operand with 32-bit byte offsets: <= 1 GiB per launch
     parts = []
     for t0 in range(0, taps, per):
         a_all = _rows(x, k3, s3, pads, t0, min(per, taps - t0), lrow)          # rows (t, ci): x sampled at tap t of every output voxel
-        parts.append(C.linear_rows(a_all.view(-1, lrow), pk))                  # (taps*Cin, Cout): the sum over the output voxels
+        if f16:
+            C._tag_amax(a_all, x_slot)                                         # copies of x's elements and zeros: max |rows| <= max |x|
+        parts.append(C.linear_rows(C.carry_amax(a_all, a_all.view(-1, lrow)), pk))     # (taps*Cin, Cout): the sum over the output voxels
     dw = parts[0] if len(parts) == 1 else torch.cat(parts)
-    return dw.view(taps, cin, cout).permute(2, 1, 0).reshape(cout, cin, *kernel)
+    return _to_torch_layout(dw, taps, cin, cout, kernel)
 
 
 def _dgrad_library(g: Tensor, x: Tensor, w: Tensor, stride: int) -> Tensor:
@@ -168,7 +275,7 @@ def _dgrad_library(g: Tensor, x: Tensor, w: Tensor, stride: int) -> Tensor:
     return dx.contiguous()
 
 
-def _dgrad_strided(g: Tensor, x: Tensor, w: Tensor, kernel, stride: int) -> Tensor:
+def _dgrad_strided(g: Tensor, x: Tensor, w: Tensor, kernel, stride: int, handed=None) -> Tensor:
     """Data gradient of a same-padded convolution of stride 2.  Default: the vendor library (ATen -> MIOpen).  Its backward-data kernels sum
     with atomics: measured, they are what kept 33 of 122 parameter gradients from reproducing bit for bit with everything else deterministic
     (exactly the parameters upstream of layer4.0.conv2's data gradient).  In the deterministic mode (autograd.set_deterministic) the gradient
@@ -184,7 +291,7 @@ def _dgrad_strided(g: Tensor, x: Tensor, w: Tensor, kernel, stride: int) -> Tens
         up[::stride, ::stride, ::stride, :cout][:g.shape[0], :g.shape[1], :g.shape[2]] = g
     else:
         up[:, ::stride, ::stride, :cout][:, :g.shape[1], :g.shape[2]] = g
-    return _conv(up, _train_pack(w, kernel, True))
+    return _conv(up, _adjoint_pack(handed, w, kernel))
 
 
 class ConvS1(torch.autograd.Function):
@@ -195,9 +302,11 @@ class ConvS1(torch.autograd.Function):
         kernel = tuple(weight.shape[2:])
         ctx.kernel, ctx.stride = kernel, int(stride)
         w = weight.detach()
-        xc = x.detach().contiguous()                            # the backward kernels index it densely
+        xc = C.carry_amax(x, x.detach().contiguous())           # the backward kernels index it densely
         ctx.save_for_backward(xc, w)
-        return _conv(xc, _train_pack(w, kernel, False, int(stride)))
+        pk = _train_pack(w, kernel, False, int(stride), want_adjoint=ctx.needs_input_grad[0])
+        ctx.adjoint = pk.pop("_adjoint", None)
+        return _conv(xc, pk)
 
     @staticmethod
     def backward(ctx, g):
@@ -209,9 +318,9 @@ class ConvS1(torch.autograd.Function):
                 # the adjoint convolution: W'[ci, co, t] = W[co, ci, flip(t)]; the kernel steps its input channels by 32, so dy (and W')
                 # are zero-padded when Cout is not a multiple
                 gd = g if g.shape[-1] % 32 == 0 else torch.nn.functional.pad(g, (0, 32 - g.shape[-1] % 32))
-                dx = _conv(gd, _train_pack(w, ctx.kernel, True))
+                dx = _conv(gd, _adjoint_pack(ctx.adjoint, w, ctx.kernel))
             else:
-                dx = _dgrad_strided(g, x, w, ctx.kernel, ctx.stride)
+                dx = _dgrad_strided(g, x, w, ctx.kernel, ctx.stride, ctx.adjoint)
         if ctx.needs_input_grad[1]:
             dw = weight_grad(x, g, ctx.kernel, ctx.stride)
         return dx, dw, None
@@ -229,10 +338,11 @@ class ConvAffineAct(torch.autograd.Function):
     def forward(ctx, x, weight, scale, shift, residual, relu, stride):
         kernel = tuple(weight.shape[2:])
         w = weight.detach()
-        pk = _train_pack(w, kernel, False, int(stride))
+        pk = _train_pack(w, kernel, False, int(stride), want_adjoint=ctx.needs_input_grad[0])
+        ctx.adjoint = pk.pop("_adjoint", None)
         pk["scale"], pk["shift"] = scale, shift
         res = None if residual is None else residual.detach().contiguous()
-        xc = x.detach().contiguous()                            # the backward kernels index it densely
+        xc = C.carry_amax(x, x.detach().contiguous())           # the backward kernels index it densely
         y = (C.conv3d_ndhwc if pk["ndim"] == 3 else C.conv2d_nhwc)(xc, pk, residual=res, relu=1 if relu else 0)
         ctx.kernel, ctx.stride, ctx.relu, ctx.has_res = kernel, int(stride), bool(relu), residual is not None
         ctx.save_for_backward(xc, w, scale, y if relu else None)
@@ -247,16 +357,24 @@ class ConvAffineAct(torch.autograd.Function):
         from . import _lib
         d_res = torch.empty_like(g) if want_res else None
         gs = torch.empty_like(g)
-        _lib.check(_lib.load().ndet_relu_affine_bwd(c_void_p(g.data_ptr()), c_void_p(y.data_ptr() if ctx.relu else 0), c_void_p(scale.data_ptr()),
-                                                    g.numel() // g.shape[-1], g.shape[-1], int(ctx.relu), c_void_p(d_res.data_ptr() if want_res else 0),
-                                                    c_void_p(gs.data_ptr()), c_void_p(torch.cuda.current_stream(g.device).cuda_stream)), "relu_affine_bwd")
+        if C.train_arithmetic() == "f16x2":      # the same pass leaves max |gs| for the fp16-pair data / weight gradients below
+            slot = C.AMAX.take(g.device)
+            _lib.check(_lib.load().ndet_relu_affine_bwd_amax(c_void_p(g.data_ptr()), c_void_p(y.data_ptr() if ctx.relu else 0), c_void_p(scale.data_ptr()),
+                                                             g.numel() // g.shape[-1], g.shape[-1], int(ctx.relu), c_void_p(d_res.data_ptr() if want_res else 0),
+                                                             c_void_p(gs.data_ptr()), c_void_p(slot.data_ptr()),
+                                                             c_void_p(torch.cuda.current_stream(g.device).cuda_stream)), "relu_affine_bwd_amax")
+            C._tag_amax(gs, slot)
+        else:
+            _lib.check(_lib.load().ndet_relu_affine_bwd(c_void_p(g.data_ptr()), c_void_p(y.data_ptr() if ctx.relu else 0), c_void_p(scale.data_ptr()),
+                                                        g.numel() // g.shape[-1], g.shape[-1], int(ctx.relu), c_void_p(d_res.data_ptr() if want_res else 0),
+                                                        c_void_p(gs.data_ptr()), c_void_p(torch.cuda.current_stream(g.device).cuda_stream)), "relu_affine_bwd")
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if ctx.stride == 1:
                 gd = gs if gs.shape[-1] % 32 == 0 else torch.nn.functional.pad(gs, (0, 32 - gs.shape[-1] % 32))
-                dx = _conv(gd, _train_pack(w, ctx.kernel, True))
+                dx = _conv(gd, _adjoint_pack(ctx.adjoint, w, ctx.kernel))
             else:
-                dx = _dgrad_strided(gs, x, w, ctx.kernel, ctx.stride)
+                dx = _dgrad_strided(gs, x, w, ctx.kernel, ctx.stride, ctx.adjoint)
         if ctx.needs_input_grad[1]:
             dw = weight_grad(x, gs, ctx.kernel, ctx.stride)
         return dx, dw, None, None, d_res, None, None
@@ -274,10 +392,10 @@ def conv_bn_act(conv: nn.Module, bn: nn.Module, x: Tensor, relu: bool = True, re
     if (torch.is_grad_enabled() and isinstance(conv, nn.Conv2d) and conv.bias is None and conv.out_channels % 4 == 0 and eligible(conv, x)
             and frozen_eval_bn(bn)):
         scale, shift = C.bn_affine(bn)
-        xb = x.permute(0, 2, 3, 1)
+        xb = C.carry_amax(x, x.permute(0, 2, 3, 1))            # (the max |x| slot a previous launch left on x travels with its views)
         rb = None if residual is None else residual.permute(0, 2, 3, 1)
-        y = ConvAffineAct.apply(xb if xb.is_contiguous() else xb.contiguous(), conv.weight, scale, shift, rb, relu, conv.stride[0])
-        return y.permute(0, 3, 1, 2)
+        y = ConvAffineAct.apply(xb if xb.is_contiguous() else C.carry_amax(xb, xb.contiguous()), conv.weight, scale, shift, rb, relu, conv.stride[0])
+        return C.carry_amax(y, y.permute(0, 3, 1, 2))
     y = bn(conv_forward(conv, x))
     if residual is not None:
         y = y + residual
@@ -312,7 +430,7 @@ class ConvT2(torch.autograd.Function):
 
 
 def eligible_transposed(conv: nn.Module, x: Tensor) -> bool:
-    return (isinstance(conv, nn.ConvTranspose3d) and C.train_arithmetic() in ("bf16x3", "bf16") and x.is_cuda and x.dtype == torch.float32 and tuple(conv.kernel_size) == (2, 2, 2)
+    return (isinstance(conv, nn.ConvTranspose3d) and C.train_arithmetic() in ("bf16x3", "bf16", "f16x2") and x.is_cuda and x.dtype == torch.float32 and tuple(conv.kernel_size) == (2, 2, 2)
             and tuple(conv.stride) == (2, 2, 2) and tuple(conv.padding) == (0, 0, 0) and tuple(conv.output_padding) == (0, 0, 0)
             and tuple(conv.dilation) == (1, 1, 1) and conv.groups == 1 and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0)
 

@@ -39,6 +39,9 @@ struct Conv3dParams {
     // they are split, by the scale the kernel derives from `amax_in`; the epilogue multiplies the accumulators by the inverse of both.
     const float* amax_in = nullptr;   // device: the input tensor's amax slot (8 per-XCD sub-slots, see conv_amax_read below)
     float winv = 1.0f;                // 1 / (weight scale)
+    const float* w_amax = nullptr;    // device, optional: the amax slot the weight planes were scaled by (training: the weights move every step and
+                                      // the weight gradient's "weight" operand is dy -- their planes are split on the device by conv_xscale of this
+                                      // slot, so 1 / scale is conv_xinv_of the same slot and no maximum ever travels to the host); replaces winv
     int nt = 0;                       // 1: the output is written with non-temporal stores (set by the launcher for outputs that cannot stay in the caches)
     float* amax_out = nullptr;        // any arithmetic, optional: max |out| is atomically maxed into the slot at amax_out (1 KiB, zeroed by the caller
                                       // before the launch) -- the next layer's amax_in without another pass over the tensor
@@ -93,9 +96,10 @@ __device__ __forceinline__ float conv_xinv_of(float amax) {
 __device__ __forceinline__ float conv_xscale(const float* amax) { return conv_xscale_of(conv_amax_read(amax)); }
 // what the accumulators are multiplied by before the epilogue's affine: 1 except in the fp16-pair arithmetic (exact: a power of two).
 // Every lane of the calling wave must be active (conv_amax_read shuffles).
-__device__ __forceinline__ float conv_oscale(const Conv3dParams& p) { return p.amax_in ? conv_xinv_of(conv_amax_read(p.amax_in)) * p.winv : 1.0f; }
+__device__ __forceinline__ float conv_winv(const Conv3dParams& p) { return p.w_amax ? conv_xinv_of(conv_amax_read(p.w_amax)) : p.winv; }
+__device__ __forceinline__ float conv_oscale(const Conv3dParams& p) { return p.amax_in ? conv_xinv_of(conv_amax_read(p.amax_in)) * conv_winv(p) : 1.0f; }
 __device__ __forceinline__ float conv_amax_in(const Conv3dParams& p) { return p.amax_in ? conv_amax_read(p.amax_in) : 0.0f; }
-__device__ __forceinline__ float conv_oscale_of(const Conv3dParams& p, float amax_in) { return p.amax_in ? conv_xinv_of(amax_in) * p.winv : 1.0f; }
+__device__ __forceinline__ float conv_oscale_of(const Conv3dParams& p, float amax_in) { return p.amax_in ? conv_xinv_of(amax_in) * conv_winv(p) : 1.0f; }
 
 // max |v| of a WORKGROUP -> one L2-local atomic on this XCD's sub-slot (non-negative floats order like their bit patterns).  Sent without
 // looking at the sub-slot first: a read in front of it (to skip the atomic when the sub-slot already holds as much) made every workgroup wait
@@ -139,7 +143,9 @@ __device__ __forceinline__ float conv_tilemin_read(const float* slot) {
 __device__ __forceinline__ void conv_guard_check(const Conv3dParams& p, float amax_in) {
     if (!p.guard || blockIdx.x != 0 || blockIdx.y != 0 || blockIdx.z != 0) return;
     const float tmin = conv_tilemin_read(p.amax_in);
-    if (threadIdx.x == 0 && amax_in * p.guard_l1 * 0x1p-39f > p.guard_tol && tmin < amax_in * 0x1p-16f) atomicOr(p.guard, 1u);
+    // weights scaled on the device (w_amax): guard_l1 is then the contraction length K and ||w||_1 <= K max|w| the bound (no host copy of the weights' norm)
+    const float l1 = p.w_amax ? p.guard_l1 * conv_amax_read(p.w_amax) : p.guard_l1;
+    if (threadIdx.x == 0 && amax_in * l1 * 0x1p-39f > p.guard_tol && tmin < amax_in * 0x1p-16f) atomicOr(p.guard, 1u);
 }
 
 // internal launchers (one per kernel family) and the shared split-K reduction

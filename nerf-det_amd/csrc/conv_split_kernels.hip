@@ -532,9 +532,11 @@ struct WgradParams {
     int OD, OH, OW;
     int L;                 // output voxels = OD OH OW
     int ksteps;            // K steps of 32 voxels (dy rows are zero-filled past L)
+    const float* x_amax = nullptr;    // fp16-pair arithmetic (SCH 1): the amax slots of x (split here, scaled by conv_xscale of its slot) and of dy (whose
+    const float* dy_amax = nullptr;   // planes ndet_wgrad_dy_planes_f16x2 scaled the same way); the epilogue multiplies by the inverse of both
 };
 
-template <int BM, int BN, bool ONE>
+template <int BM, int BN, int SCH>
 __global__ __launch_bounds__(256, 2) void k_wgrad_split(const WgradParams g, const Conv3dParams p, const uint16_t* __restrict__ gsplit) {
     constexpr int NTHR = 256, WGM = 2, WGN = 2;
     constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(const WgradParams g, con
     constexpr int VT = 32 / VG;             // consecutive voxels per thread (4 / 2): a thread transposes a VT x 4 block in registers
     constexpr int RPB = NTHR / 4, BR = BN / RPB;
     static_assert((VT == 4 || VT == 2) && BR >= 1 && MT >= 1 && NT >= 1, "tile too small for the thread count");
-    constexpr int NPL = ONE ? 1 : 3;
+    constexpr int NPL = Spl<SCH>::NPL, WPL = Spl<SCH>::WPL;      // SCH 0: three bf16 planes, 1: two fp16 planes of the pre-scaled operands, 2: one bf16 plane
     constexpr int APL = BM * SPL_RS, BPL = BN * SPL_RS;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds16[];
     uint16_t* As = lds16;
@@ -557,6 +559,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(const WgradParams g, con
     const int cq = tid % CQ, vg = tid / CQ;
     const int bkg = tid & 3, brow_ = tid >> 2;
 
+    const float xs = SCH == 1 ? conv_xscale(g.x_amax) : 1.0f;
+    const float osc = SCH == 1 ? conv_xinv_of(conv_amax_read(g.x_amax)) * conv_xinv_of(conv_amax_read(g.dy_amax)) : 1.0f;
     int it_begin = 0, it_end = g.ksteps;
     if (p.splits > 1) {
         it_begin = (int)((int64_t)g.ksteps * blockIdx.z / p.splits);
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(const WgradParams g, con
                 if (++oh[i] == g.OH) { oh[i] = 0; ++od[i]; }
             }
         }
-        const uint16_t* bt = bbase_g + (int64_t)nit * 3 * wtile;
+        const uint16_t* bt = bbase_g + (int64_t)nit * WPL * wtile;
 #pragma unroll
         for (int i = 0; i < BR; ++i)
 #pragma unroll
@@ -620,24 +624,16 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(const WgradParams g, con
             uint16_t* dst = As + row * SPL_RS + ((((k0 >> 3) ^ ((row >> 4) & 3)) << 3) | (k0 & 7));
             if (VT == 4) {
                 uint2 s0, s1, s2;
-                const float4 v = make_float4(rf[e], rf[4 + e], rf[8 + e], rf[12 + e]);
-                if (ONE) s0 = make_uint2(spl_pack(v.x, v.y), spl_pack(v.z, v.w));
-                else spl_split4(v, s0, s1, s2);
+                spl_split<SCH>(make_float4(rf[e], rf[4 + e], rf[8 + e], rf[12 + e]), xs, s0, s1, s2);
                 *reinterpret_cast<uint2*>(dst) = s0;
-                if (!ONE) {
-                    *reinterpret_cast<uint2*>(dst + APL) = s1;
-                    *reinterpret_cast<uint2*>(dst + 2 * APL) = s2;
-                }
+                if (NPL > 1) *reinterpret_cast<uint2*>(dst + APL) = s1;
+                if (NPL > 2) *reinterpret_cast<uint2*>(dst + 2 * APL) = s2;
             } else {
-                const float a_ = rf[e], b_ = rf[4 + e];
-                const uint32_t o0 = spl_pack(a_, b_);
+                uint32_t o0, o1, o2;
+                spl_split2<SCH>(rf[e], rf[4 + e], xs, o0, o1, o2);
                 *reinterpret_cast<uint32_t*>(dst) = o0;
-                if (!ONE) {
-                    const float r0 = a_ - spl_lo(o0), r1 = b_ - spl_hi(o0);
-                    const uint32_t o1 = spl_pack(r0, r1);
-                    *reinterpret_cast<uint32_t*>(dst + APL) = o1;
-                    *reinterpret_cast<uint32_t*>(dst + 2 * APL) = spl_pack(r0 - spl_lo(o1), r1 - spl_hi(o1));
-                }
+                if (NPL > 1) *reinterpret_cast<uint32_t*>(dst + APL) = o1;
+                if (NPL > 2) *reinterpret_cast<uint32_t*>(dst + 2 * APL) = o2;
             }
         }
 #pragma unroll
@@ -679,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(const WgradParams g, con
                     for (int ta_ = 0; ta_ < MT; ++ta_)
 #pragma unroll
                         for (int tb_ = 0; tb_ < NT; ++tb_)
-                            acc[ta_][tb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][ta_], fb[pb][tb_], acc[ta_][tb_], 0, 0, 0);
+                            acc[ta_][tb_] = spl_mfma32<SCH>(fa[pa][ta_], fb[pb][tb_], acc[ta_][tb_]);
                 }
         }
         __syncthreads();
@@ -700,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(const WgradParams g, con
         }
         __syncthreads();
         float mx_unused = 0.0f;
-        conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, 0, blockIdx.z, mx_unused, 1.0f);
+        conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, 0, blockIdx.z, mx_unused, osc);
         __syncthreads();
     }
 }
@@ -1867,6 +1863,118 @@ extern "C" int ndet_split_weights_bf16x3_torch(const float* w_torch, int taps, i
     return NDET_OK;
 }
 
+
+// Both packs of a TRAINING step's weight in one pass over it: the layer's own planes (taps, Cin/32, WPL, Cout, 32) and the planes of its data gradient
+// W'[t][ci][co] = W[co][ci][taps - 1 - t], (taps, ceil(Cout/32), WPL, Cin, 32) (Cout zero-padded) -- SCH 0: three bf16 planes; SCH 1: two fp16 planes of
+// w * conv_xscale(amax slot), the scale never leaving the device (ndet_conv_ndhwc_train reads its inverse from the same slot).  k_split_weights_torch
+// reads the torch layout (Cout, Cin, taps) with a stride of `taps` floats between neighbouring lanes (a 1024 x 1024 x 27 weight: 559 us, 0.2 TB/s of
+// reads) and runs once per pack; here a workgroup takes a 32 x 32 (co, ci) block with all its taps -- 32 contiguous runs of 32 taps floats -- through
+// LDS, and every (tap, plane) of either pack leaves as one contiguous 2 KB piece.
+template <int SCH>
+__global__ __launch_bounds__(1024) void k_split_weights_train(const float* __restrict__ w, int taps, int Cout, int Cin, const float* __restrict__ amax,
+                                                              uint16_t* __restrict__ fwd, uint16_t* __restrict__ adj) {
+    constexpr int WPL = Spl<SCH>::WPL;
+    extern __shared__ __attribute__((aligned(16))) float wt_tile[];      // [32 co][32 ci x taps + 1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int run = 32 * taps, pitch = run + 1;
+    const float xs = SCH == 1 ? conv_xscale(amax) : 1.0f;
+    for (int r = wave; r < 32; r += 16) {
+        const int co = co0 + r;
+        const float* src = w + ((int64_t)co * Cin + ci0) * taps;
+        for (int c = lane; c < run; c += 64) wt_tile[r * pitch + c] = co < Cout ? src[c] * xs : 0.0f;
+    }
+    __syncthreads();
+    const int stepsF = Cin / CBK, stepsA = (Cout + CBK - 1) / CBK;
+    // one item = an element pair of one (tap, row): 16 pairs per row, 32 rows, taps x 512 items; a wave covers 4 rows = 256 contiguous bytes per plane
+    for (int item = tid; item < taps * 512; item += 1024) {
+        const int tap = item >> 9, r = (item >> 4) & 31, cp = item & 15;
+        uint32_t o[3];
+        // the layer's own planes: row = output channel, pair along the input channels
+        spl_split2<SCH>(wt_tile[r * pitch + (2 * cp) * taps + tap], wt_tile[r * pitch + (2 * cp + 1) * taps + tap], 1.0f, o[0], o[1], o[2]);
+        if (co0 + r < Cout) {
+            uint16_t* dst = fwd + (((int64_t)tap * stepsF + blockIdx.x) * WPL * Cout + (co0 + r)) * CBK + 2 * cp;
+#pragma unroll
+            for (int pl = 0; pl < WPL; ++pl) *reinterpret_cast<uint32_t*>(dst + (int64_t)pl * Cout * CBK) = o[pl];
+        }
+        // the data gradient's planes: row = input channel, pair along the (padded) output channels, taps flipped
+        if (adj) {
+            spl_split2<SCH>(wt_tile[(2 * cp) * pitch + r * taps + tap], wt_tile[(2 * cp + 1) * pitch + r * taps + tap], 1.0f, o[0], o[1], o[2]);
+            uint16_t* dst = adj + (((int64_t)(taps - 1 - tap) * stepsA + blockIdx.y) * WPL * Cin + (ci0 + r)) * CBK + 2 * cp;
+#pragma unroll
+            for (int pl = 0; pl < WPL; ++pl) *reinterpret_cast<uint32_t*>(dst + (int64_t)pl * Cin * CBK) = o[pl];
+        }
+    }
+}
+
+// The weight gradient's last step: dw_rows ((tap, ci) rows x Cout, what the GEMMs write) -> torch's (Cout, Cin, taps) layout.  The same 32 x 32 x taps
+// block through LDS as above, the other way round: 128-byte row pieces in, one contiguous run of 32 taps floats per output channel out.  (As
+// `dw.view(taps, Cin, Cout).permute(2, 1, 0).reshape(...)` this was ATen's generic strided copy: ~2.4 ms of the training step for 108 M parameters.)
+__global__ __launch_bounds__(1024) void k_wgrad_to_torch(const float* __restrict__ rows, int taps, int Cout, int Cin, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float wt_tile[];      // [32 co][32 ci x taps + 1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int run = 32 * taps, pitch = run + 1;
+    for (int item = tid; item < taps * 1024; item += 1024) {
+        const int tap = item >> 10, r = (item >> 5) & 31, c = item & 31;       // r: input channel, c: output channel
+        if (co0 + c < Cout) wt_tile[c * pitch + r * taps + tap] = rows[((int64_t)tap * Cin + ci0 + r) * Cout + co0 + c];
+    }
+    __syncthreads();
+    for (int r = wave; r < 32; r += 16) {
+        const int co = co0 + r;
+        if (co >= Cout) break;
+        float* dst = out + ((int64_t)co * Cin + ci0) * taps;
+        for (int c = lane; c < run; c += 64) dst[c] = wt_tile[r * pitch + c];
+    }
+}
+
+extern "C" int ndet_wgrad_to_torch(const float* dw_rows, int taps, int Cout, int Cin, float* dw_torch, void* stream) {
+    const char* fn = "ndet_wgrad_to_torch";
+    NDET_REQUIRE(dw_rows && dw_torch, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(taps > 0 && taps <= 27 && Cout > 0 && Cin > 0 && Cin % 32 == 0 && (Cout + 31) / 32 <= 65535, NDET_E_UNSUPPORTED, "%s: 1..27 taps, Cin %% 32 == 0", fn);
+    const size_t lds = (size_t)32 * (32 * taps + 1) * sizeof(float);
+    if (lds > 48 * 1024) {
+        static bool attr_set[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_wgrad_to_torch, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (32 * 27 + 1) * 4);
+            NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(k_wgrad_to_torch, dim3(Cin / 32, (Cout + 31) / 32), dim3(1024), lds, (hipStream_t)stream, dw_rows, taps, Cout, Cin, dw_torch);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
+
+extern "C" int ndet_split_weights_train(const float* w_torch, int taps, int Cout, int Cin, int arith, const float* w_amax, uint16_t* planes,
+                                        uint16_t* planes_adjoint, void* stream) {
+    const char* fn = "ndet_split_weights_train";
+    NDET_REQUIRE(w_torch && planes, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(taps > 0 && taps <= 27 && Cout > 0 && Cin > 0, NDET_E_UNSUPPORTED, "%s: 1..27 taps, positive sizes", fn);
+    NDET_REQUIRE(arith == 0 || arith == 1, NDET_E_INVALID, "%s: arith must be 0 (bf16x3) or 1 (fp16 pair)", fn);
+    NDET_REQUIRE((arith == 1) == (w_amax != nullptr), NDET_E_INVALID, "%s: the amax slot belongs to the fp16-pair arithmetic", fn);
+    NDET_REQUIRE(Cin % CBK == 0 && (Cout + CBK - 1) / CBK <= 65535, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of %d", fn, Cin, CBK);
+    const size_t lds = (size_t)32 * (32 * taps + 1) * sizeof(float);
+    const void* kfn = arith == 1 ? (const void*)k_split_weights_train<1> : (const void*)k_split_weights_train<0>;
+    if (lds > 48 * 1024) {                           // per device: a process may drive several (one rank per GPU is the rule, not a guarantee)
+        static bool attr_set[2][64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_set[arith][dev]) {
+            hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (32 * 27 + 1) * 4);
+            NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
+            if (dev >= 0 && dev < 64) attr_set[arith][dev] = true;
+        }
+    }
+    const dim3 grid(Cin / CBK, (Cout + CBK - 1) / CBK);
+    if (arith == 1) hipLaunchKernelGGL(k_split_weights_train<1>, grid, dim3(1024), lds, (hipStream_t)stream, w_torch, taps, Cout, Cin, w_amax, planes, planes_adjoint);
+    else hipLaunchKernelGGL(k_split_weights_train<0>, grid, dim3(1024), lds, (hipStream_t)stream, w_torch, taps, Cout, Cin, w_amax, planes, planes_adjoint);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
+
 static int conv_split_entry(const char* fn, int max_order, const float* in_amax, float w_inv_scale, float* out_amax, const float* in, const uint16_t* w_planes,
                             float* out, int D, int H, int W, int Cin, int Cout, const int* kernel, const int* stride, const int* pad, int transposed,
                             const float* scale, const float* shift, const float* residual, int residual_up2, int relu, int splits, int tile,
@@ -1888,8 +1996,8 @@ extern "C" int ndet_conv_ndhwc_bf16(const float* in, const uint16_t* w_planes, f
                             residual_up2, relu, splits, tile, workspace, stream);
 }
 
-struct ConvGuard { unsigned* flag; float l1, l1_3, tol; };
-static thread_local ConvGuard g_guard = {nullptr, 0.0f, 0.0f, 0.0f};     // handed from the *_guarded entry points to the shared argument checks below (per call)
+struct ConvGuard { unsigned* flag; float l1, l1_3, tol; const float* w_amax; };
+static thread_local ConvGuard g_guard = {nullptr, 0.0f, 0.0f, 0.0f, nullptr};     // handed from the *_guarded / *_train entry points to the shared argument checks below (per call)
 
 extern "C" int ndet_conv_ndhwc_guarded(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
                                        const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
@@ -1897,10 +2005,26 @@ extern "C" int ndet_conv_ndhwc_guarded(const float* in, const uint16_t* w_planes
                                        const float* in_amax, float w_inv_scale, float* out_amax, void* workspace, float guard_l1, float guard_tol,
                                        unsigned* guard, void* stream) {
     NDET_REQUIRE(!guard || (guard_l1 >= 0.0f && guard_tol > 0.0f), NDET_E_INVALID, "ndet_conv_ndhwc_guarded: the guard needs guard_l1 >= 0 and guard_tol > 0");
-    g_guard = ConvGuard{arith == 1 ? guard : nullptr, guard_l1, 0.0f, guard_tol};
+    g_guard = ConvGuard{arith == 1 ? guard : nullptr, guard_l1, 0.0f, guard_tol, nullptr};
     const int rc = ndet_conv_ndhwc_arith(in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, transposed, scale, shift, residual, residual_up2, relu, splits,
                                          tile, arith, in_amax, w_inv_scale, out_amax, workspace, stream);
-    g_guard = ConvGuard{nullptr, 0.0f, 0.0f, 0.0f};
+    g_guard = ConvGuard{nullptr, 0.0f, 0.0f, 0.0f, nullptr};
+    return rc;
+}
+
+// The fp16-pair launch of the training step: the weight planes were scaled ON THE DEVICE by conv_xscale of the slot `w_amax` (ndet_split_weights_train:
+// the optimizer moves the weights every step; ndet_wgrad_dy_planes_f16x2: the weight gradient's "weight" operand is dy), so the kernels take 1 / scale
+// from the same slot.  `guard_k` = the contraction length (taps x Cin): the range guard bounds ||w||_1 by guard_k max|w|; guard null = no check.
+extern "C" int ndet_conv_ndhwc_train(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
+                                     const int* kernel, const int* stride, const int* pad, const float* scale, const float* shift, const float* residual,
+                                     int relu, int splits, int tile, const float* in_amax, const float* w_amax, float* out_amax, void* workspace,
+                                     float guard_k, float guard_tol, unsigned* guard, void* stream) {
+    NDET_REQUIRE(w_amax != nullptr, NDET_E_INVALID, "ndet_conv_ndhwc_train: the weight planes' amax slot is required");
+    NDET_REQUIRE(!guard || (guard_k >= 0.0f && guard_tol > 0.0f), NDET_E_INVALID, "ndet_conv_ndhwc_train: the guard needs guard_k >= 0 and guard_tol > 0");
+    g_guard = ConvGuard{guard, guard_k, 0.0f, guard_tol, w_amax};
+    const int rc = ndet_conv_ndhwc_arith(in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, 0, scale, shift, residual, 0, relu, splits, tile, 1, in_amax, 1.0f,
+                                         out_amax, workspace, stream);
+    g_guard = ConvGuard{nullptr, 0.0f, 0.0f, 0.0f, nullptr};
     return rc;
 }
 
@@ -1965,7 +2089,7 @@ static int conv_split_entry(const char* fn, int max_order, const float* in_amax,
     p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
     p.max_order = max_order;
     p.amax_in = in_amax; p.winv = w_inv_scale; p.amax_out = out_amax;
-    p.guard = g_guard.flag; p.guard_l1 = g_guard.l1; p.guard_tol = g_guard.tol;
+    p.guard = g_guard.flag; p.guard_l1 = g_guard.l1; p.guard_tol = g_guard.tol; p.w_amax = g_guard.w_amax;
     if (transposed) {
         for (int a = 0; a < 3; ++a)
             NDET_REQUIRE(kernel[a] == 2 && stride[a] == 2 && pad[a] == 0, NDET_E_UNSUPPORTED, "%s: transposed conv supports kernel 2 stride 2 pad 0 only", fn);
@@ -2095,27 +2219,27 @@ extern "C" int ndet_conv_chain_arith(const float* in, const uint16_t* w_planes, 
     return NDET_OK;
 }
 
-template <int BM, int BN, bool ONE>
+template <int BM, int BN, int SCH>
 static int wgrad_launch(const WgradParams& g, const Conv3dParams& p, const uint16_t* gplanes, hipStream_t st) {
     dim3 grid(p.M / BM, (p.Cout + BN - 1) / BN, p.splits);
-    size_t lds = (size_t)(ONE ? 1 : 3) * (BM + BN) * SPL_RS * sizeof(uint16_t);
+    size_t lds = (size_t)Spl<SCH>::NPL * (BM + BN) * SPL_RS * sizeof(uint16_t);
     const size_t cs = (size_t)(BM / 2) * (BN + 4) * sizeof(float);
     if (cs > lds) lds = cs;
-    hipLaunchKernelGGL((k_wgrad_split<BM, BN, ONE>), grid, dim3(256), lds, st, g, p, gplanes);
+    hipLaunchKernelGGL((k_wgrad_split<BM, BN, SCH>), grid, dim3(256), lds, st, g, p, gplanes);
     return NDET_OK;
 }
 
-extern "C" int ndet_wgrad_split(const float* x_ndhwc, int D, int H, int W, int Cin, const int* kernel, const int* stride, const int* pad,
-                                const uint16_t* dy_planes, int Cout, int lrow, int splits, int max_order, void* workspace, float* dw_rows,
-                                void* stream) {
-    const char* fn = "ndet_wgrad_split";
+static int wgrad_split_entry(const char* fn, const float* x_ndhwc, int D, int H, int W, int Cin, const int* kernel, const int* stride, const int* pad,
+                             const uint16_t* dy_planes, int Cout, int lrow, int splits, int max_order, const float* x_amax, const float* dy_amax, void* workspace,
+                             float* dw_rows, void* stream) {
     NDET_REQUIRE(x_ndhwc && kernel && stride && pad && dy_planes && dw_rows, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && lrow > 0 && lrow % CBK == 0, NDET_E_INVALID, "%s: bad sizes", fn);
     NDET_REQUIRE(Cin % 64 == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of 64", fn, Cin);
-    NDET_REQUIRE(max_order == 0 || max_order == 2, NDET_E_INVALID, "%s: bad arithmetic", fn);
+    NDET_REQUIRE(max_order == 0 || max_order == 1 || max_order == 2, NDET_E_INVALID, "%s: bad arithmetic", fn);
+    NDET_REQUIRE((max_order == 1) == (x_amax != nullptr && dy_amax != nullptr), NDET_E_INVALID, "%s: the fp16-pair arithmetic needs both amax slots (the others none)", fn);
     NDET_REQUIRE((((uintptr_t)x_ndhwc | (uintptr_t)dy_planes | (uintptr_t)dw_rows) & 15) == 0, NDET_E_UNSUPPORTED, "%s: pointers must be 16-byte aligned", fn);
     WgradParams g;
-    g.x = x_ndhwc; g.D = D; g.H = H; g.W = W; g.Cin = Cin;
+    g.x = x_ndhwc; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.x_amax = x_amax; g.dy_amax = dy_amax;
     for (int a = 0; a < 3; ++a)
         NDET_REQUIRE(kernel[a] >= 1 && kernel[a] <= 7 && stride[a] >= 1 && stride[a] <= 4 && pad[a] >= 0 && pad[a] < kernel[a], NDET_E_UNSUPPORTED,
                      "%s: kernel/stride/pad out of range on axis %d", fn, a);
@@ -2138,14 +2262,32 @@ extern "C" int ndet_wgrad_split(const float* x_ndhwc, int D, int H, int W, int C
     NDET_REQUIRE(p.splits <= g.ksteps, NDET_E_INVALID, "%s: splits=%d exceeds the %d K steps", fn, p.splits, g.ksteps);
     NDET_REQUIRE(p.splits == 1 || workspace != nullptr, NDET_E_INVALID, "%s: split-K needs a workspace", fn);
     hipStream_t st = (hipStream_t)stream;
-    const bool one = max_order == 0, wide = Cout > 64, big = Cin % 128 == 0;
+    const bool wide = Cout > 64, big = Cin % 128 == 0;
+    const int sch = max_order == 0 ? 2 : (max_order == 1 ? 1 : 0);
     int rc;
-    if (big && wide) rc = one ? wgrad_launch<128, 128, true>(g, p, dy_planes, st) : wgrad_launch<128, 128, false>(g, p, dy_planes, st);
-    else if (big) rc = one ? wgrad_launch<128, 64, true>(g, p, dy_planes, st) : wgrad_launch<128, 64, false>(g, p, dy_planes, st);
-    else if (wide) rc = one ? wgrad_launch<64, 128, true>(g, p, dy_planes, st) : wgrad_launch<64, 128, false>(g, p, dy_planes, st);
-    else rc = one ? wgrad_launch<64, 64, true>(g, p, dy_planes, st) : wgrad_launch<64, 64, false>(g, p, dy_planes, st);
+#define NDET_WGRAD_TILE(BM, BN) (sch == 2 ? wgrad_launch<BM, BN, 2>(g, p, dy_planes, st) : (sch == 1 ? wgrad_launch<BM, BN, 1>(g, p, dy_planes, st) : wgrad_launch<BM, BN, 0>(g, p, dy_planes, st)))
+    if (big && wide) rc = NDET_WGRAD_TILE(128, 128);
+    else if (big) rc = NDET_WGRAD_TILE(128, 64);
+    else if (wide) rc = NDET_WGRAD_TILE(64, 128);
+    else rc = NDET_WGRAD_TILE(64, 64);
+#undef NDET_WGRAD_TILE
     if (rc != NDET_OK) return rc;
     NDET_CHECK_LAUNCH(fn);
     return conv_splitk_reduce_launch(p, st, fn);
+}
+
+extern "C" int ndet_wgrad_split(const float* x_ndhwc, int D, int H, int W, int Cin, const int* kernel, const int* stride, const int* pad,
+                                const uint16_t* dy_planes, int Cout, int lrow, int splits, int max_order, void* workspace, float* dw_rows,
+                                void* stream) {
+    NDET_REQUIRE(max_order == 0 || max_order == 2, NDET_E_INVALID, "ndet_wgrad_split: max_order 0 (bf16) or 2 (bf16x3); the fp16-pair form is ndet_wgrad_split_f16x2");
+    return wgrad_split_entry("ndet_wgrad_split", x_ndhwc, D, H, W, Cin, kernel, stride, pad, dy_planes, Cout, lrow, splits, max_order, nullptr, nullptr, workspace, dw_rows, stream);
+}
+
+// The same implicit GEMM in the fp16-pair arithmetic: dy_planes from ndet_wgrad_dy_planes_f16x2 (two planes per K step, scaled by its slot), x split in
+// the kernel under the scale of x_amax, three products.
+extern "C" int ndet_wgrad_split_f16x2(const float* x_ndhwc, int D, int H, int W, int Cin, const int* kernel, const int* stride, const int* pad,
+                                      const uint16_t* dy_planes, int Cout, int lrow, int splits, const float* x_amax, const float* dy_amax, void* workspace,
+                                      float* dw_rows, void* stream) {
+    return wgrad_split_entry("ndet_wgrad_split_f16x2", x_ndhwc, D, H, W, Cin, kernel, stride, pad, dy_planes, Cout, lrow, splits, 1, x_amax, dy_amax, workspace, dw_rows, stream);
 }
 

@@ -8,6 +8,7 @@
 //                      (data_augment_utils.py:410-424, un-normalised), the camera centre repeated per ray
 //                      (formating.py:70-75) and the target colours gathered from the de-normalised frame.
 #include "ndet_common.hpp"
+#include "spl_common.hpp"
 
 __global__ __launch_bounds__(256) void k_normalize_views(const uint8_t* __restrict__ frames, const int* __restrict__ ids, int n_sel, int H, int W,
                                                          float m0, float m1, float m2, float i0, float i1, float i2, float s0, float s1,
@@ -174,33 +175,55 @@ extern "C" int ndet_wgrad_rows(const float* x_ndhwc, int D, int H, int W, int C,
 //     gs = gm * scale[c]     what the data / weight gradients of the convolution receive
 // one pass over channels-last rows instead of three library launches (compare, multiply, multiply).
 // ------------------------------------------------------------------------------------------------
+// Each workgroup walks ONE contiguous range of float4s (so that, with `amax`, its maximum is a region's: conv_tilemin_read) and, when asked, leaves
+// max |gs| in the slot -- gs is the operand of the layer's data and weight gradients, which in the fp16-pair arithmetic would otherwise each start
+// with an ndet_amax_f32 pass over it.
 __global__ __launch_bounds__(256) void k_relu_affine_bwd(const float4* __restrict__ g, const float4* __restrict__ y, const float4* __restrict__ scale,
-                                                        int64_t n4, int c4, int relu, float4* __restrict__ gm, float4* __restrict__ gs) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    float4 v = g[i];
-    if (relu) {
-        const float4 t = y[i];
-        v.x = t.x > 0.f ? v.x : 0.f; v.y = t.y > 0.f ? v.y : 0.f; v.z = t.z > 0.f ? v.z : 0.f; v.w = t.w > 0.f ? v.w : 0.f;
+                                                        int64_t n4, int c4, int relu, float4* __restrict__ gm, float4* __restrict__ gs, float* __restrict__ amax) {
+    const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
+    float mx = 0.0f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        float4 v = g[i];
+        if (relu) {
+            const float4 t = y[i];
+            v.x = t.x > 0.f ? v.x : 0.f; v.y = t.y > 0.f ? v.y : 0.f; v.z = t.z > 0.f ? v.z : 0.f; v.w = t.w > 0.f ? v.w : 0.f;
+        }
+        if (gm) gm[i] = v;
+        const float4 s = scale[i % c4];
+        const float4 o = make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
+        gs[i] = o;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
-    if (gm) gm[i] = v;
-    const float4 s = scale[i % c4];
-    gs[i] = make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
+    if (amax) conv_amax_commit(amax, mx);
 }
 
-extern "C" int ndet_relu_affine_bwd(const float* dy, const float* y, const float* scale, int64_t rows, int C, int relu, float* d_identity,
-                                    float* d_conv, void* stream) {
-    const char* fn = "ndet_relu_affine_bwd";
+static int relu_affine_bwd_entry(const char* fn, const float* dy, const float* y, const float* scale, int64_t rows, int C, int relu, float* d_identity,
+                                 float* d_conv, float* d_conv_amax, void* stream) {
     NDET_REQUIRE(dy && scale && d_conv && (y || !relu), NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, NDET_E_UNSUPPORTED, "%s: C=%d must be a positive multiple of 4", fn, C);
     NDET_REQUIRE((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)scale | (uintptr_t)d_identity | (uintptr_t)d_conv) & 15) == 0, NDET_E_UNSUPPORTED,
                  "%s: pointers must be 16-byte aligned", fn);
     const int64_t n4 = rows * (C / 4);
-    NDET_REQUIRE((n4 + 255) / 256 < ((int64_t)1 << 31), NDET_E_UNSUPPORTED, "%s: tensor too large", fn);
-    hipLaunchKernelGGL(k_relu_affine_bwd, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)dy, (const float4*)y,
-                       (const float4*)scale, n4, C / 4, relu, (float4*)d_identity, (float4*)d_conv);
+    int64_t blocks = (n4 + 1023) / 1024;            // >= 4 float4s per thread
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_relu_affine_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)dy, (const float4*)y,
+                       (const float4*)scale, n4, C / 4, relu, (float4*)d_identity, (float4*)d_conv, d_conv_amax);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
+}
+
+extern "C" int ndet_relu_affine_bwd(const float* dy, const float* y, const float* scale, int64_t rows, int C, int relu, float* d_identity,
+                                    float* d_conv, void* stream) {
+    return relu_affine_bwd_entry("ndet_relu_affine_bwd", dy, y, scale, rows, C, relu, d_identity, d_conv, nullptr, stream);
+}
+
+// the same pass leaving max |d_conv| in a zeroed amax slot (the fp16-pair data / weight gradients read their operand's scale from it)
+extern "C" int ndet_relu_affine_bwd_amax(const float* dy, const float* y, const float* scale, int64_t rows, int C, int relu, float* d_identity,
+                                         float* d_conv, float* d_conv_amax, void* stream) {
+    NDET_REQUIRE(d_conv_amax != nullptr, NDET_E_INVALID, "ndet_relu_affine_bwd_amax: null slot");
+    return relu_affine_bwd_entry("ndet_relu_affine_bwd_amax", dy, y, scale, rows, C, relu, d_identity, d_conv, d_conv_amax, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -210,14 +233,11 @@ extern "C" int ndet_relu_affine_bwd(const float* dy, const float* y, const float
 // nn.Conv3d / nn.Conv2d, mmdet3d/models/necks/imvoxelnet.py:22-67,233-260.  64 voxels x 64 channels per workgroup through an LDS
 // transpose; a thread then owns 16 consecutive voxels of one channel: splits them and writes 32 bytes per plane.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t pk_bf16x2(float x, float y) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-    const b2 v = __builtin_convertvector((f2){x, y}, b2);
-    return __builtin_bit_cast(uint32_t, v);
-}
-
-__global__ __launch_bounds__(256) void k_wgrad_dy_planes(const float* __restrict__ g, int L, int C, int lrow, uint16_t* __restrict__ planes) {
+// F16: two fp16 planes of dy * conv_xscale(amax slot) per K step (the fp16-pair weight gradient; 1 / scale is read from the same slot by the GEMM)
+template <bool F16>
+__global__ __launch_bounds__(256) void k_wgrad_dy_planes(const float* __restrict__ g, int L, int C, int lrow, const float* __restrict__ amax, uint16_t* __restrict__ planes) {
+    constexpr int WPL = F16 ? 2 : 3;
+    const float xs = F16 ? conv_xscale(amax) : 1.0f;
     __shared__ float tile[64][65];
     const int j0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -235,14 +255,11 @@ __global__ __launch_bounds__(256) void k_wgrad_dy_planes(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const float a = tile[chunk * 32 + half * 16 + 2 * i][tx], b = tile[chunk * 32 + half * 16 + 2 * i + 1][tx];
-        o[0][i] = pk_bf16x2(a, b);
-        const float ra = a - __uint_as_float(o[0][i] << 16), rb = b - __uint_as_float(o[0][i] & 0xffff0000u);
-        o[1][i] = pk_bf16x2(ra, rb);
-        o[2][i] = pk_bf16x2(ra - __uint_as_float(o[1][i] << 16), rb - __uint_as_float(o[1][i] & 0xffff0000u));
+        spl_split2<F16 ? 1 : 0>(a, b, xs, o[0][i], o[1][i], o[2][i]);
     }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-        uint4* dst = reinterpret_cast<uint4*>(planes + (((int64_t)kc * 3 + pl) * C + co) * 32 + half * 16);
+    for (int pl = 0; pl < WPL; ++pl) {
+        uint4* dst = reinterpret_cast<uint4*>(planes + (((int64_t)kc * WPL + pl) * C + co) * 32 + half * 16);
         dst[0] = make_uint4(o[pl][0], o[pl][1], o[pl][2], o[pl][3]);
         dst[1] = make_uint4(o[pl][4], o[pl][5], o[pl][6], o[pl][7]);
     }
@@ -253,8 +270,20 @@ extern "C" int ndet_wgrad_dy_planes(const float* dy_rows_by_voxel, int L, int Co
     NDET_REQUIRE(dy_rows_by_voxel && planes, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(L > 0 && Cout > 0 && lrow >= L && lrow % 32 == 0, NDET_E_INVALID, "%s: bad sizes (L=%d, lrow=%d)", fn, L, lrow);
     NDET_REQUIRE((((uintptr_t)planes) & 15) == 0 && (Cout + 63) / 64 <= 65535, NDET_E_UNSUPPORTED, "%s: planes must be 16-byte aligned", fn);
-    hipLaunchKernelGGL(k_wgrad_dy_planes, dim3((lrow + 63) / 64, (Cout + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy_rows_by_voxel, L, Cout, lrow,
-                       planes);
+    hipLaunchKernelGGL(k_wgrad_dy_planes<false>, dim3((lrow + 63) / 64, (Cout + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy_rows_by_voxel, L, Cout, lrow,
+                       (const float*)nullptr, planes);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
+
+// fp16-pair form: (lrow/32, 2, Cout, 32) planes of dy scaled by conv_xscale of its amax slot (ndet_amax_f32 / a producing epilogue)
+extern "C" int ndet_wgrad_dy_planes_f16x2(const float* dy_rows_by_voxel, int L, int Cout, int lrow, const float* dy_amax, uint16_t* planes, void* stream) {
+    const char* fn = "ndet_wgrad_dy_planes_f16x2";
+    NDET_REQUIRE(dy_rows_by_voxel && planes && dy_amax, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(L > 0 && Cout > 0 && lrow >= L && lrow % 32 == 0, NDET_E_INVALID, "%s: bad sizes (L=%d, lrow=%d)", fn, L, lrow);
+    NDET_REQUIRE((((uintptr_t)planes) & 15) == 0 && (Cout + 63) / 64 <= 65535, NDET_E_UNSUPPORTED, "%s: planes must be 16-byte aligned", fn);
+    hipLaunchKernelGGL(k_wgrad_dy_planes<true>, dim3((lrow + 63) / 64, (Cout + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy_rows_by_voxel, L, Cout, lrow,
+                       dy_amax, planes);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }

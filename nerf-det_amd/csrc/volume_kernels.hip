@@ -19,7 +19,7 @@ void ndet_set_error(const char* fmt, ...) {
 }
 
 int g_ndet_deterministic_scatter = 0;      // ndet_common.hpp::ndet_scatter_add
-extern "C" int ndet_version(void) { return 106; }
+extern "C" int ndet_version(void) { return 107; }
 extern "C" const char* ndet_last_error(void) { return g_err; }
 
 #define VOX_PER_TILE 16  // one workgroup = 4 waves x 4 voxels = 16 consecutive voxels (one z column at Z=16)

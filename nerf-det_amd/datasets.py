@@ -286,7 +286,11 @@ class DefaultFormatBundle3D:
             results["lightpos"] = lp.unsqueeze(1).repeat(1, rd.shape[1], 1)
             results["gt_images"] = torch.from_numpy(np.ascontiguousarray(np.stack(results["gt_images"], axis=0)))
             if isinstance(results["gt_depths"], list) and len(results["gt_depths"]) != 0:
-                results["gt_depths"] = torch.from_numpy(np.ascontiguousarray(np.stack(results["gt_depths"], axis=0)))
+                gd = np.ascontiguousarray(np.stack(results["gt_depths"], axis=0))
+                results["gt_depths"] = torch.from_numpy(gd)
+                # the rays WITH depth, as the training-time ray draw wants them (render_ray.py:386-404), found here on the loader's side: on the
+                # device the same ``nonzero`` hands its count to the host through a stream synchronisation (nerfdet_amd.rays.begin_selection)
+                results["depth_rays"] = torch.from_numpy(np.flatnonzero(gd.reshape(-1) > 0))
             results["denorm_images"] = torch.from_numpy(np.ascontiguousarray(np.stack([im.transpose(2, 0, 1) for im in results["denorm_images"]],
                                                                                    axis=0))).float()
         if "gt_labels_3d" in results:
@@ -307,6 +311,8 @@ class Collect3D:
         data = dict(img_metas={k: results[k] for k in self.meta_keys if k in results})
         for k in self.keys:
             data[k] = results[k]
+        if "gt_depths" in self.keys and "depth_rays" in results:      # travels with the depth maps it was derived from (DefaultFormatBundle3D above)
+            data["depth_rays"] = results["depth_rays"]
         return data
 
 

@@ -160,6 +160,8 @@ class nerfdet(BaseDetector):
         if "raydirs" in kwargs:
             rb = dict(ray_o=kwargs["lightpos"], ray_d=kwargs["raydirs"], gt_rgb=kwargs["gt_images"],
                       gt_depth=kwargs["gt_depths"], nerf_sizes=kwargs["nerf_sizes"], denorm_images=kwargs["denorm_images"])
+            if kwargs.get("depth_rays") is not None:
+                rb["depth_rays"] = kwargs["depth_rays"]          # the loader's nonzero(gt_depths > 0) (datasets.py): no host sync for the ray draw
         return rb
 
     def forward_train(self, img, img_metas, gt_bboxes_3d, gt_labels_3d, **kwargs):

@@ -42,13 +42,14 @@ class LayerStack(nn.Module):
         return self.skip is not None and i > 0 and i % self.skip == 0
 
     def forward(self, x):
+        from .autograd import linear_rows_train      # training on many rows: split weight / bias gradients (autograd.LinearRows)
         x0 = x
         for i, layer in enumerate(self.hidden_layers):
-            x = F.relu(layer(x))
+            x = linear_rows_train(x, layer, relu=True)
             if self._rejoin(i):
                 x = torch.cat([x, x0], dim=-1)
         if hasattr(self, "output_layer"):
-            x = self.output_layer(x)
+            x = linear_rows_train(x, self.output_layer)
         return x
 
 

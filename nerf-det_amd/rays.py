@@ -267,6 +267,13 @@ def begin_selection(ray_batch):
     rays = ray_batch["ray_d"].view(-1, 3)
     if len(gt_depth) == 0:
         return None, rays.shape[0], rays.device
+    given = ray_batch.get("depth_rays")
+    if given is not None and (given.dim() == 1 or given.shape[0] == 1):
+        # found by the loader on the host, before the upload (datasets.py: DefaultFormatBundle3D; batches of one scene, config:133): the count is a
+        # shape.  On the device the same ``nonzero`` reads its count back through a stream synchronisation -- with the step's log read lazily
+        # (train.StepLog) the host would wait there for the whole previous step's backward.
+        kept = given.reshape(-1)
+        return kept, int(kept.numel()), rays.device
     kept = torch.nonzero(gt_depth.view(-1) > 0).view(-1)
     return kept, int(kept.numel()), rays.device
 

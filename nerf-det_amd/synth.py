@@ -48,9 +48,12 @@ def train_scene(n_views: int, img_hw=(240, 320), t_views: int = 10, n_boxes: int
     ray_d = -ray_o / ray_o.norm(dim=-1, keepdim=True) + 0.35 * torch.randn(1, t_views, nray, 3, generator=g)
     ctr = torch.rand(n_boxes, 3, generator=g) * torch.tensor([5.0, 5.0, 1.5]) + torch.tensor([-2.5, -2.5, -0.5])
     size = 0.6 + torch.rand(n_boxes, 3, generator=g)
-    return dict(img=torch.randn(1, n_views, 3, h, w, generator=g), img_metas=[ring_scene_meta(n_views, img_hw)],
-                denorm_images=torch.rand(1, n_views, 3, h, w, generator=g), lightpos=ray_o, raydirs=ray_d,
-                gt_images=torch.rand(1, t_views, nray, 3, generator=g), gt_depths=torch.rand(1, t_views, rh, rw, generator=g) * 5 + 0.5,
+    img, denorm, gt_images = torch.randn(1, n_views, 3, h, w, generator=g), torch.rand(1, n_views, 3, h, w, generator=g), torch.rand(1, t_views, nray, 3, generator=g)
+    gt_depths = torch.rand(1, t_views, rh, rw, generator=g) * 5 + 0.5
+    return dict(img=img, img_metas=[ring_scene_meta(n_views, img_hw)],
+                denorm_images=denorm, lightpos=ray_o, raydirs=ray_d,
+                gt_images=gt_images, gt_depths=gt_depths,
+                depth_rays=torch.nonzero(gt_depths.view(-1) > 0).view(1, -1),       # as the dataset pipeline leaves it (datasets.py)
                 nerf_sizes=[torch.tensor([[rh, rw, 3]])],
                 gt_bboxes_3d=[DepthInstance3DBoxes(torch.cat([ctr, size], 1), box_dim=6, with_yaw=False, origin=(0.5, 0.5, 0.5))],
                 gt_labels_3d=[torch.randint(0, 18, (n_boxes,), generator=g)])

@@ -64,17 +64,52 @@ def build_optimizer(model: torch.nn.Module, lr: float = 2e-4, weight_decay: floa
     return torch.optim.AdamW([dict(params=rest), dict(params=bb, lr=lr * backbone_lr_mult)], lr=lr, weight_decay=weight_decay, **(dict(fused=True) if fused else {}))
 
 
-def train_one_step(model, data: Dict, optimizer, grad_clip: float = 35.0) -> Dict:
+class StepLog:
+    """The logged scalars of one step on their way to the host: stacked on the device, copied into pinned memory without blocking, readable once
+    the copy's event has passed.  Lets the caller queue step i + 1 before it reads step i's numbers -- the launch queue never drains at a step
+    boundary -- where ``float(v)`` per scalar (what mmdet's ``_parse_losses`` does with ``.item()``) stalls the host until the device is idle."""
+
+    def __init__(self, names, values):
+        self.names = list(names)
+        dev = torch.stack([v.detach().float().reshape(()) for v in values])
+        self.host = torch.empty(dev.shape, dtype=torch.float32, pin_memory=dev.is_cuda)
+        self.host.copy_(dev, non_blocking=True)
+        self.event = torch.cuda.Event() if dev.is_cuda else None
+        if self.event is not None:
+            self.event.record(torch.cuda.current_stream(dev.device))
+
+    def ready(self) -> bool:
+        return self.event is None or self.event.query()
+
+    def get(self) -> Dict[str, float]:
+        """Blocks until THIS step's values have arrived (not until the device is idle)."""
+        if self.event is not None:
+            self.event.synchronize()
+        return {k: float(v) for k, v in zip(self.names, self.host.tolist())}
+
+
+def train_one_step(model, data: Dict, optimizer, grad_clip: float = 35.0, lazy_log: bool = False) -> Dict:
     """One iteration of the runner's loop: forward, backward (DDP all-reduces the gradients while it runs),
-    clip (config:173), step."""
+    clip (config:173), step.  ``lazy_log``: ``out["log"]`` is a :class:`StepLog` (``log_vars`` + ``grad_norm``, read with ``.get()``) instead of
+    host floats -- the step then ends without a host synchronisation."""
     optimizer.zero_grad(set_to_none=True)
+    module = model.module if isinstance(model, DistributedDataParallel) else model
+    if any(p.is_cuda for p in module.parameters()):
+        from . import conv_train
+        conv_train.prepare_step(module)                         # fp16-pair training: every convolution weight's max |w| in two launches
     out = model.train_step(data, optimizer, defer_log=True)     # logged scalars stay on the device until the whole step is queued
     out["loss"].backward()
-    module = model.module if isinstance(model, DistributedDataParallel) else model
     params = [p for p in module.parameters() if p.requires_grad and p.grad is not None]
     norm = torch.nn.utils.clip_grad_norm_(params, grad_clip) if grad_clip and params else None
     optimizer.step()
-    out["log_vars"] = {k: float(v) for k, v in out["log_vars"].items()}     # the step's only host sync after its first launches
+    names = list(out["log_vars"]) + (["grad_norm"] if norm is not None else [])
+    log = StepLog(names, list(out["log_vars"].values()) + ([norm] if norm is not None else []))
+    if lazy_log:
+        out["log"] = log
+        out["log_vars"] = None
+        return out
+    vals = log.get()                                            # the step's only host sync after its first launches
     if norm is not None:
-        out["grad_norm"] = float(norm)
+        out["grad_norm"] = vals.pop("grad_norm")
+    out["log_vars"] = vals
     return out

@@ -31,6 +31,9 @@ def map_features_2d(features: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
     rows = f.permute(0, 2, 3, 1)  # (n_v,h,w,C) view
     if not rows.is_contiguous():  # an [:h,:w] crop of a padded map
         rows = rows.contiguous()
+    from .autograd import LINEAR_ROWS_MIN, LinearRows
+    if torch.is_grad_enabled() and rows.is_cuda and rows.numel() // rows.shape[-1] >= LINEAR_ROWS_MIN:
+        return LinearRows.apply(rows, weight, bias, False).permute(0, 3, 1, 2)     # weight gradient over 192 000 rows: split (autograd.LinearRows)
     return F.linear(rows, weight, bias).permute(0, 3, 1, 2)
 
 

@@ -8,6 +8,16 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["f16x2", "bf16x3"], autouse=True)
+def train_arith(request):
+    """Every test of this file on both training arithmetics: the three-product fp16 pairs with device-side scales (the default) and the
+    six-product bf16x3 kernels (conv3d.TRAIN_F16X2 = False)."""
+    import nerfdet_amd.conv3d as C
+    prev, C.TRAIN_F16X2 = C.TRAIN_F16X2, request.param == "f16x2"
+    yield request.param
+    C.TRAIN_F16X2 = prev
+
+
 def _rel(a, b):
     return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
 
@@ -185,3 +195,36 @@ def test_implicit_weight_gradient_equals_the_staged_form(device, dims, cin, cout
     exact = torch.nn.grad.conv3d_weight(xd, (cout, cin) + k3, gd, stride=s3, padding=p3).reshape(staged.shape)
     assert implicit.shape == staged.shape
     assert _rel(implicit.cpu().double(), exact) <= 2e-5 and _rel(staged.cpu().double(), exact) <= 2e-5
+
+
+@pytest.mark.parametrize("cout,cin,kernel", [(96, 64, (3, 3, 3)), (25, 128, (3, 3, 3)), (64, 32, (1, 1)), (256, 64, (3, 3)), (33, 32, (2, 2, 2))])
+def test_both_weight_packs_in_one_launch(device, train_arith, cout, cin, kernel):
+    """ndet_split_weights_train against the one-pack-per-launch kernel (bf16x3: the same planes bit for bit, both packs) and against the
+    definition of the fp16 pair (hi = fp16(w s), lo = fp16(w s - hi), s the power of two that puts max |w| in [2^14, 2^15))."""
+    import math
+    from ctypes import c_void_p
+    from nerfdet_amd import _lib, conv_train
+    torch.manual_seed(cout + cin)
+    w = (torch.randn(cout, cin, *kernel) * 0.07).to(device)
+    taps = math.prod(kernel)
+    planes, adj, slot = conv_train._split_both(w, taps, train_arith, True)
+    kp = (cout + 31) // 32 * 32
+    wt = w.reshape(cout, cin, taps)
+    fwd_ref = wt.permute(2, 0, 1)                                          # (taps, Cout, Cin)
+    adj_ref = torch.zeros(taps, cin, kp, device=device)
+    adj_ref[:, :, :cout] = wt.flip(2).permute(2, 1, 0)                     # W'[t][ci][co] = W[co][ci][taps-1-t]
+    if train_arith == "bf16x3":
+        st = c_void_p(torch.cuda.current_stream().cuda_stream)
+        for adjoint, got in ((0, planes), (1, adj)):
+            ref = torch.empty_like(got)
+            _lib.check(_lib.load().ndet_split_weights_bf16x3_torch(c_void_p(w.data_ptr()), taps, cout, cin, adjoint, c_void_p(ref.data_ptr()), st), "split")
+            assert torch.equal(got, ref), adjoint
+        return
+    scale = 2.0 ** (15 - math.frexp(float(w.abs().max()))[1])
+    for got, ref, no, ki in ((planes, fwd_ref, cout, cin), (adj, adj_ref, cin, kp)):
+        hi = (ref * scale).half()
+        lo = (ref * scale - hi.float()).half()
+        want = torch.stack([hi, lo], 0).view(2, taps, no, ki // 32, 32).permute(1, 3, 0, 2, 4).contiguous()      # (taps, K/32, 2, No, 32)
+        assert torch.equal(got.view(torch.float16), want)
+    from nerfdet_amd.conv3d import amax_value
+    assert amax_value(slot) == float(w.abs().max())

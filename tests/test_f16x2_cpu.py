@@ -42,7 +42,10 @@ def test_weight_scale_and_layer_rule():
     prev = C.set_arithmetic("f16x2")
     try:
         assert C.layer_arithmetic(C.F16_MIN_KSTEPS) == "f16x2" and C.layer_arithmetic(C.F16_MIN_KSTEPS - 1) == "bf16x3"
+        assert C.train_arithmetic() == ("f16x2" if C.TRAIN_F16X2 else "bf16x3")      # training follows the inference arithmetic unless switched off
+        keep, C.TRAIN_F16X2 = C.TRAIN_F16X2, False
         assert C.train_arithmetic() == "bf16x3"
+        C.TRAIN_F16X2 = keep
         C.set_arithmetic("bf16")
         assert C.layer_arithmetic(1) == "bf16" and C.train_arithmetic() == "bf16"
     finally:

@@ -155,3 +155,23 @@ def test_ssim_closed_form_cases():
     # symmetric, and bounded by 1
     z = rs.rand(19, 23, 3)
     assert abs(both(x, z) - both(z, x)) < 1e-14 and both(x, z) < 1.0
+
+
+def test_depth_rays_from_the_loader_replace_the_device_nonzero():
+    """The training-time ray draw keeps the rays WITH depth (render_ray.py:386-404).  The loader finds them on the host (batch key
+    ``depth_rays``) so that the step needs no stream synchronisation for their count; rays.begin_selection must hand back exactly what
+    ``nonzero(gt_depth > 0)`` gives, and fall back to that when the key is missing."""
+    import torch
+    from nerfdet_amd import rays
+    from nerfdet_amd.datasets import Collect3D
+    from nerfdet_amd.synth import train_scene
+    scene = train_scene(3, (48, 64), t_views=2, n_boxes=2, seed=3)
+    scene["gt_depths"][0, 0, 5:9, 7:30] = 0.0                      # holes, as real depth maps have
+    scene["depth_rays"] = torch.nonzero(scene["gt_depths"].view(-1) > 0).view(1, -1)
+    rb = dict(ray_d=scene["raydirs"], gt_depth=scene["gt_depths"], depth_rays=scene["depth_rays"])
+    kept, n, _ = rays.begin_selection(rb)
+    ref, n_ref, _ = rays.begin_selection(dict(ray_d=scene["raydirs"], gt_depth=scene["gt_depths"]))
+    assert n == n_ref < scene["gt_depths"].numel() and torch.equal(kept, ref)
+    # the pipeline's collector passes the key on whenever it passes the depth maps
+    out = Collect3D(keys=["gt_depths"])(dict(gt_depths=scene["gt_depths"][0], depth_rays=scene["depth_rays"][0]))
+    assert "depth_rays" in out and "depth_rays" not in Collect3D(keys=["img"])(dict(img=0, depth_rays=1))

@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--arith", default=None)
     ap.add_argument("--depth-supervise", type=int, default=1)
     ap.add_argument("--views", type=int, default=40)
+    ap.add_argument("--lazy-log", type=int, default=1, help="1: a step's logged scalars are read from pinned memory after the next step has been queued "
+                                                            "(train.StepLog); 0: host floats at the end of every step (one device drain per step)")
+    ap.add_argument("--train-f16x2", type=int, default=1, help="0: the training convolutions on the six-product bf16x3 kernels")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -98,6 +101,7 @@ def main():
     dev = torch.device("cuda", local)
     if args.arith:
         C3.set_arithmetic(args.arith)
+    C3.TRAIN_F16X2 = bool(args.train_f16x2)
     torch.manual_seed(0)
     det = build_nerfdet(50, depth_supervise=bool(args.depth_supervise))
     with torch.no_grad():
@@ -119,11 +123,21 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ticks = [t0]
+    prev = None
     for i in range(args.steps):
         state["step"] = i
-        out = train_one_step(model, data, opt)          # ends with the step's one host sync (the logged scalars)
+        cur = train_one_step(model, data, opt, lazy_log=bool(args.lazy_log))     # lazy: step i's scalars are read after step i + 1 is queued
+        if args.lazy_log:
+            if prev is not None:
+                prev["log"].get()
+            prev = cur
+        else:
+            out = cur
         ticks.append(time.perf_counter())
     torch.cuda.synchronize()
+    if args.lazy_log:
+        vals = prev["log"].get()
+        out = dict(grad_norm=vals.pop("grad_norm", None), log_vars=vals)
     if grouped:
         torch.distributed.barrier()
     dt = D.max_over_ranks((time.perf_counter() - t0) / args.steps, dev)
@@ -133,15 +147,16 @@ def main():
         pct = lambda q: per_step[min(len(per_step) - 1, int(round(q * (len(per_step) - 1))))]
         n_conv_steps = len([i for i in range(args.steps) if i % 4 == 0])
         spans = rec.span_ms()
-        arith = C3.train_arithmetic()        # the fp16-pair mode trains on bf16x3 (its frozen, inference-form prefix runs "/f16x2" launches: 3 products)
-        conv_peak = {"bf16x3": 2500.0 / 6.0, "bf16": 2500.0, "f32": 157.3}[arith]
-        peak_of = lambda name: 2500.0 / 3.0 if name.endswith("/f16x2") else conv_peak
-        peak_note = {"bf16x3": "dense bf16 MFMA peak 2500 TFLOP/s / 6 issued products per algorithmic multiply-add (3 for the fp16-pair launches of the "
+        arith = C3.train_arithmetic()        # fp16 pairs (3 products) unless conv3d.TRAIN_F16X2 is off (then bf16x3: 6; the frozen prefix stays "/f16x2")
+        conv_peak = {"f16x2": 2500.0 / 3.0, "bf16x3": 2500.0 / 6.0, "bf16": 2500.0, "f32": 157.3}[arith]
+        peak_of = lambda name: 2500.0 / 3.0 if name.endswith("/f16x2") else (2500.0 / 6.0 if arith == "f16x2" else conv_peak)
+        peak_note = {"f16x2": "dense fp16 MFMA peak 2500 TFLOP/s / 3 issued products per algorithmic multiply-add (6 for the launches pinned to bf16x3)",
+                     "bf16x3": "dense bf16 MFMA peak 2500 TFLOP/s / 6 issued products per algorithmic multiply-add (3 for the fp16-pair launches of the "
                                "frozen prefix)", "bf16": "dense bf16 MFMA peak", "f32": "dense fp32-input MFMA peak"}[arith]
         conv = {k: v for k, v in spans.items() if v and v[0][1].get("kind") == "conv"}
         by_kernel = {k: [sum(i["flops"] for _, i in v), sum(ms for ms, _ in v), len(v)] for k, v in conv.items()}
         line = dict(metric="training steps/sec (cfg3 shapes)", value=world / dt, unit="scenes/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                    ms_per_step=dt * 1e3, median_ms=pct(0.5), p10_ms=pct(0.1), p90_ms=pct(0.9), higher_is_better=True, scaling="weak", dtype=arith + (" (frozen prefix: f16x2)" if C3.ARITHMETIC == "f16x2" else ""),
+                    ms_per_step=dt * 1e3, median_ms=pct(0.5), p10_ms=pct(0.1), p90_ms=pct(0.9), higher_is_better=True, scaling="weak", dtype=arith + (" (frozen prefix: f16x2)" if C3.ARITHMETIC == "f16x2" and arith != "f16x2" else ""),
                     data="synthetic",
                     config=dict(workload=f"cfg3 shapes, {world} GPU(s) x 1 scene/step, {arith} convolutions: {args.views} source views 240x320 + 10 NeRF target "
                                          f"views, 40x40x16 voxels, 2048 rays x 64 samples, {'5' if args.depth_supervise else '4'} losses + backward + clip + AdamW"
