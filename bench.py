@@ -305,6 +305,7 @@ def train_probe(det_gpu, batch):
         d = json.loads(lines[-1])
         keep = {"ms": d["ms_per_step"], "median_ms": d["median_ms"], "p10_ms": d["p10_ms"], "p90_ms": d["p90_ms"], "steps": d["steps"], "warmup": d["warmup"],
                 "dtype": d["dtype"], "scenes_per_s": d["value"], "workload": d["config"]["workload"], "log_vars": d["log_vars"], "peak_mem_GB": d["peak_mem_GB"],
+                "host_sync": d.get("host_sync"), "ms_host_read_every_step": d.get("ms_per_step_host_read_every_step"),
                 "note": "tools/bench_train.py --steps 8 --warmup 3 in a child process after the timed region; one rank, no DDP"}
         for k in ("roofline", "roofline_all_convolutions", "roofline_k4_forward", "roofline_k4_backward"):
             if k in d:

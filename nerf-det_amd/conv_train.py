@@ -233,7 +233,8 @@ def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pa
         from ctypes import c_void_p
         from . import _lib
         planes = pk["w_f16"][0] if f16 else C.split_planes(pk)
-        bm, bn = (128 if cin % 128 == 0 else 64), (128 if cout > 64 else 64)
+        bm = 128 if cin % 128 == 0 else 64
+        bn = 256 if (f16 and bm == 128 and cout % 256 == 0) else (128 if cout > 64 else 64)      # (the library's own choice: ndet_wgrad_split*)
         tiles = (taps * cin // bm) * ((cout + bn - 1) // bn)
         ksteps = lrow // 32
         splits = max(1, min(32, ksteps // 8, -(-768 // tiles)))

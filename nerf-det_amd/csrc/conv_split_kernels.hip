@@ -1706,13 +1706,16 @@ static int split_launch_halo_any(const Conv3dParams& p, hipStream_t st, const ch
 static int64_t g_nt_bytes = (int64_t)32 << 20;
 static bool g_order2 = true;
 static int64_t conv_nt_bytes() { return g_nt_bytes; }
+static int g_wgrad_wide = 1;     // measurement knob "wgrad_wide": 0 = the 128 x 128 weight-gradient tile for every layer
+
 extern "C" int ndet_measurement_knob(const char* name, int64_t value) {
     const char* fn = "ndet_measurement_knob";
     NDET_REQUIRE(name, NDET_E_INVALID, "%s: null name", fn);
     if (!strcmp(name, "nt_bytes")) { NDET_REQUIRE(value >= 0, NDET_E_INVALID, "%s: nt_bytes must be >= 0", fn); g_nt_bytes = value; return NDET_OK; }
     if (!strcmp(name, "order2")) { NDET_REQUIRE(value == 0 || value == 1, NDET_E_INVALID, "%s: order2 is 0 or 1", fn); g_order2 = value != 0; return NDET_OK; }
     if (!strcmp(name, "deterministic_scatter")) { NDET_REQUIRE(value == 0 || value == 1, NDET_E_INVALID, "%s: deterministic_scatter is 0 or 1", fn); g_ndet_deterministic_scatter = (int)value; return NDET_OK; }
-    ndet_set_error("%s: unknown knob '%s' (nt_bytes, order2, deterministic_scatter)", fn, name);
+    if (!strcmp(name, "wgrad_wide")) { NDET_REQUIRE(value == 0 || value == 1, NDET_E_INVALID, "%s: wgrad_wide is 0 or 1", fn); g_wgrad_wide = (int)value; return NDET_OK; }
+    ndet_set_error("%s: unknown knob '%s' (nt_bytes, order2, deterministic_scatter, wgrad_wide)", fn, name);
     return NDET_E_INVALID;
 }
 extern "C" int ndet_amax_slot_floats(void) { return NDET_AMAX_SUB * NDET_AMAX_STRIDE; }
@@ -2266,7 +2269,21 @@ static int wgrad_split_entry(const char* fn, const float* x_ndhwc, int D, int H,
     const int sch = max_order == 0 ? 2 : (max_order == 1 ? 1 : 0);
     int rc;
 #define NDET_WGRAD_TILE(BM, BN) (sch == 2 ? wgrad_launch<BM, BN, 2>(g, p, dy_planes, st) : (sch == 1 ? wgrad_launch<BM, BN, 1>(g, p, dy_planes, st) : wgrad_launch<BM, BN, 0>(g, p, dy_planes, st)))
-    if (big && wide) rc = NDET_WGRAD_TILE(128, 128);
+    // 256 output channels per workgroup where the layer has them (fp16 pairs; the 3-plane arithmetic's LDS tiles would not leave room for two
+    // workgroups per CU): the kernel is bound by what it pulls through L2 -- every (tap, channel tile) re-reads dy, every column tile re-reads x;
+    // measured on the neck's 27-tap 256 -> 256 layer at 128 x 128: 2.8 GB per launch, 6.2 TB/s -- and the wider tile halves the x side
+    if (big && sch == 1 && Cout % 256 == 0 && g_wgrad_wide) {
+        static bool attr_set[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_wgrad_split<128, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (256 + 4) * 4);
+            NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
+        rc = wgrad_launch<128, 256, 1>(g, p, dy_planes, st);
+    }
+    else if (big && wide) rc = NDET_WGRAD_TILE(128, 128);
     else if (big) rc = NDET_WGRAD_TILE(128, 64);
     else if (wide) rc = NDET_WGRAD_TILE(64, 128);
     else rc = NDET_WGRAD_TILE(64, 64);

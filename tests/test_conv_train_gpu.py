@@ -172,7 +172,8 @@ def test_bottleneck_training_forward_backward_vs_fp64(device):
 
 @pytest.mark.parametrize("dims,cin,cout,kernel,stride,pads", [((12, 10, 6), 128, 64, (3, 3, 3), 1, None), ((9, 8, 6), 64, 128, (3, 3, 3), 2, None),
                                                               ((8, 8, 4), 128, 25, (3, 3, 3), 1, None), ((10, 6, 4), 256, 96, (2, 2, 2), 2, (0, 0, 0)),
-                                                              ((3, 11, 14), 64, 64, (3, 3), 2, None), ((2, 9, 12), 192, 256, (1, 1), 1, None)])
+                                                              ((3, 11, 14), 64, 64, (3, 3), 2, None), ((2, 9, 12), 192, 256, (1, 1), 1, None),
+                                                              ((7, 6, 5), 128, 256, (3, 3, 3), 1, None), ((3, 9, 10), 256, 512, (3, 3), 1, None)])      # (the 128 x 256 tile of the fp16-pair form)
 def test_implicit_weight_gradient_equals_the_staged_form(device, dims, cin, cout, kernel, stride, pads):
     """k_wgrad_split (x read in place, transposed into LDS) against the staged form (tap copies + one GEMM): the same products summed in
     another order, and both against an fp64 evaluation of the sum."""

@@ -142,6 +142,17 @@ def main():
         torch.distributed.barrier()
     dt = D.max_over_ranks((time.perf_counter() - t0) / args.steps, dev)
     trace.recorder = None
+    # the same step with its scalars read on the host at the end of EVERY step (what mmdet's _parse_losses does with .item()): a few steps after
+    # the timed region, reported next to the figure above so that nobody has to guess what the lazy read is worth
+    dt_sync = None
+    if args.lazy_log:
+        n_sync = max(2, min(4, args.steps))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_sync):
+            train_one_step(model, data, opt)
+        torch.cuda.synchronize()
+        dt_sync = D.max_over_ranks((time.perf_counter() - t1) / n_sync, dev)
     if rank == 0:
         per_step = sorted((b - a) * 1e3 for a, b in zip(ticks, ticks[1:]))
         pct = lambda q: per_step[min(len(per_step) - 1, int(round(q * (len(per_step) - 1))))]
@@ -161,7 +172,12 @@ def main():
                     config=dict(workload=f"cfg3 shapes, {world} GPU(s) x 1 scene/step, {arith} convolutions: {args.views} source views 240x320 + 10 NeRF target "
                                          f"views, 40x40x16 voxels, 2048 rays x 64 samples, {'5' if args.depth_supervise else '4'} losses + backward + clip + AdamW"
                                          + (", DDP over RCCL" if grouped else ""), scenes_per_step=world),
-                    log_vars=out["log_vars"], grad_norm=out.get("grad_norm"), peak_mem_GB=torch.cuda.max_memory_allocated() / 1e9)
+                    log_vars=out["log_vars"], grad_norm=out.get("grad_norm"), peak_mem_GB=torch.cuda.max_memory_allocated() / 1e9,
+                    host_sync=("none inside the timed region's steps: each step's logged scalars are read from pinned memory after the next step has been "
+                               "queued (train.StepLog), the rays with depth come from the loader (batch key depth_rays)" if args.lazy_log else
+                               "the logged scalars are read on the host at the end of every step"))
+        if dt_sync is not None:
+            line["ms_per_step_host_read_every_step"] = dt_sync * 1e3
         if grouped:
             from nerfdet_amd.train import ddp_bucket_plan
             line["ddp_buckets_bytes"] = ddp_bucket_plan(det)

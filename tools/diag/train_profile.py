@@ -48,6 +48,12 @@ def main():
     print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=70))
     print("# grouped by input shape")
     print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=50, max_shapes_column_width=90))
+    print("# the elementwise / copy / reduction operators by input shape (device time over the profiled steps)")
+    by_shape = prof.key_averages(group_by_input_shape=True)
+    for op in ("aten::copy_", "aten::add", "aten::add_", "aten::sum", "aten::mul", "aten::fill_", "aten::cat", "aten::div", "aten::threshold_backward", "aten::where", "aten::index"):
+        rows = sorted((e for e in by_shape if e.key == op), key=lambda e: -e.self_device_time_total)[:10]
+        for e in rows:
+            print(f"{op:26s} {e.self_device_time_total / 1e3:8.3f} ms {e.count:5d} calls  {str(e.input_shapes)[:150]}")
     print("# grouped by call site")
     print(prof.key_averages(group_by_stack_n=6).table(sort_by="self_cuda_time_total", row_limit=50, max_name_column_width=40, max_src_column_width=110))
 
