@@ -471,7 +471,7 @@ int ndet_wgrad_dy_planes(const float* dy_rows_by_voxel, int L, int Cout, int lro
 int ndet_wgrad_dy_planes_f16x2(const float* dy_rows_by_voxel, int L, int Cout, int lrow, const float* dy_amax, uint16_t* planes, void* stream);
 int ndet_wgrad_split_f16x2(const float* x_ndhwc, int D, int H, int W, int Cin, const int* kernel, const int* stride, const int* pad,
                            const uint16_t* dy_planes, int Cout, int lrow, int splits, const float* x_amax, const float* dy_amax, void* workspace,
-                           float* dw_rows, void* stream);
+                           float* dw_rows, int keep_partials, void* stream);
 
 /* Both weight packs of one training step in ONE pass over a torch-layout weight (Cout, Cin, taps <= 27): planes = the layer's own
  * (taps, Cin/32, P, Cout, 32), planes_adjoint (may be null) = its data gradient's (taps, ceil32(Cout)/32, P, Cin, 32), W'[t][ci][co] = W[co][ci][taps-1-t]
@@ -484,18 +484,22 @@ int ndet_split_weights_train(const float* w_torch, int taps, int Cout, int Cin, 
 
 /* The weight gradient in torch's layout: dw_rows ((tap, ci) rows x Cout floats, what ndet_wgrad_split* and the staged GEMM write) ->
  * dw_torch (Cout, Cin, taps), the layout autograd hands to the optimizer for nn.Conv3d / nn.Conv2d.weight
- * (mmdet3d/models/necks/imvoxelnet.py:22-67,233-260).  32 x 32 x taps blocks through LDS, coalesced on both sides; taps <= 27, Cin % 32 == 0. */
-int ndet_wgrad_to_torch(const float* dw_rows, int taps, int Cout, int Cin, float* dw_torch, void* stream);
+ * (mmdet3d/models/necks/imvoxelnet.py:22-67,233-260).  32 x 32 x taps blocks through LDS, coalesced on both sides; taps <= 27, Cin % 32 == 0.
+ * splits > 1: dw_rows is the split-K WORKSPACE of a launch made with keep_partials = 1 (ndet_conv_ndhwc_train, ndet_wgrad_split_f16x2) -- `splits`
+ * partial sums taps * Cin * Cout floats apart, added here in index order (what the separate reduction pass would have done, bit for bit). */
+int ndet_wgrad_to_torch(const float* dw_rows, int splits, int taps, int Cout, int Cin, float* dw_torch, void* stream);
 
 /* The fp16-pair convolution launch of the training step (forward and data gradient of the convolutions of
  * mmdet3d/models/necks/imvoxelnet.py:22-67,233-260, dense_heads/imvoxel_head_v2.py:45-58,444-449 and the trainable ResNet / FPN layers behind
  * detectors/nerfdet.py:140-142): ndet_conv_ndhwc_guarded with arith = 1 whose weight planes were scaled on the device -- by ndet_split_weights_train,
  * or, for the weight-gradient GEMM over ndet_wgrad_rows' tap copies, dy's planes from ndet_wgrad_dy_planes_f16x2 -- so 1 / (weight scale) is taken
- * from the slot w_amax instead of a host float.  guard (may be null): the range guard with ||w||_1 bounded by guard_k * max|w|, guard_k = taps * Cin. */
+ * from the slot w_amax instead of a host float.  guard (may be null): the range guard with ||w||_1 bounded by guard_k * max|w|, guard_k = taps * Cin.
+ * keep_partials = 1 (weight-gradient GEMMs; no affine / residual / ReLU / out_amax): a split-K launch leaves its partial sums in the workspace for
+ * ndet_wgrad_to_torch instead of running the reduction pass; `out` is then not written. */
 int ndet_conv_ndhwc_train(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout, const int* kernel,
                           const int* stride, const int* pad, const float* scale, const float* shift, const float* residual, int relu, int splits,
                           int tile, const float* in_amax, const float* w_amax, float* out_amax, void* workspace, float guard_k, float guard_tol,
-                          unsigned* guard, void* stream);
+                          unsigned* guard, int keep_partials, void* stream);
 
 /* Backward of the fused epilogue y = relu(conv * scale + shift (+ identity)) -- convolution + frozen eval-mode BatchNorm + ReLU (+ the
  * bottleneck's identity) of the trainable ResNet stages (mmdet Bottleneck.forward behind mmdet3d/models/detectors/nerfdet.py:140;

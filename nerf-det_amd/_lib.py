@@ -82,10 +82,10 @@ SIGNATURES = {
     "ndet_stem_pack_weights_f16x2": ([_P, c_float, _P, _P], c_int),
     "ndet_wgrad_dy_planes": ([_P, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_wgrad_dy_planes_f16x2": ([_P, c_int, c_int, c_int, _P, _P, _P], c_int),
-    "ndet_wgrad_split_f16x2": ([_P] + [c_int] * 4 + [_P, _P, _P, _P] + [c_int] * 3 + [_P, _P, _P, _P, _P], c_int),
-    "ndet_wgrad_to_torch": ([_P, c_int, c_int, c_int, _P, _P], c_int),
+    "ndet_wgrad_split_f16x2": ([_P] + [c_int] * 4 + [_P, _P, _P, _P] + [c_int] * 3 + [_P, _P, _P, _P, c_int, _P], c_int),
+    "ndet_wgrad_to_torch": ([_P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_split_weights_train": ([_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P], c_int),
-    "ndet_conv_ndhwc_train": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P], c_int),
+    "ndet_conv_ndhwc_train": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P], c_int),
     "ndet_relu_affine_bwd": ([_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P], c_int),
     "ndet_relu_affine_bwd_amax": ([_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P], c_int),
     "ndet_wgrad_split": ([_P] + [c_int] * 4 + [_P, _P, _P, _P] + [c_int] * 4 + [_P, _P, _P], c_int),

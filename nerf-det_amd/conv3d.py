@@ -397,13 +397,17 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
         # training packs (conv_train.py): planes scaled on the device by the slot pk["w_amax"]; plain convolutions only
         assert not transposed and not residual_up2
         planes, in_amax = pk["w_f16"][0], amax_of(x)
+        keep = bool(pk.get("keep_partials"))       # weight-gradient GEMMs: a split-K launch leaves its partials for ndet_wgrad_to_torch (no reduction pass)
+        want_amax = want_amax and not keep
         out_amax = AMAX.take(x.device) if want_amax else None
         gw = guard_word(x.device) if pk.get("guard", True) else None
         _launch(flops, lambda: check(lib.ndet_conv_ndhwc_train(_ptr(x), _ptr(planes), _ptr(out), d, h, w, pk["cin"], pk["cout"], i3(kernel), i3(stride), i3(pad),
                                                                _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), relu, splits, tile, _ptr(in_amax),
                                                                _ptr(pk["w_amax"]), _ptr(out_amax), _ptr(ws), float(kernel[0] * kernel[1] * kernel[2] * pk["cin"]),
-                                                               GUARD_TOL, _ptr(gw), st),
+                                                               GUARD_TOL, _ptr(gw), int(keep), st),
                                      "conv_ndhwc_train"), arith, tile, nbytes)
+        if keep:
+            pk["_partials"] = (ws.view(torch.float32), splits) if splits > 1 else None     # (splits == 1: the launch wrote `out` as usual)
         if want_amax:
             _tag_amax(out, out_amax)
         return out

@@ -172,14 +172,16 @@ def _rows(x: Tensor, k3, stride3, pads, t0: int, n_taps: int, lrow: int) -> Tens
     return out
 
 
-def _to_torch_layout(dw_rows: Tensor, taps: int, cin: int, cout: int, kernel) -> Tensor:
-    """(taps * Cin, Cout) GEMM rows -> (Cout, Cin, *kernel): one coalesced pass (csrc: k_wgrad_to_torch) instead of ATen's strided copy."""
+def _to_torch_layout(dw_rows: Tensor, taps: int, cin: int, cout: int, kernel, splits: int = 1) -> Tensor:
+    """(taps * Cin, Cout) GEMM rows -> (Cout, Cin, *kernel): one coalesced pass (csrc: k_wgrad_to_torch) instead of ATen's strided copy.  ``splits`` > 1:
+    ``dw_rows`` is a split-K workspace, its partial sums are added on the way (fixed order)."""
     if taps > 27 or cin % 32:
+        assert splits == 1
         return dw_rows.view(taps, cin, cout).permute(2, 1, 0).reshape(cout, cin, *kernel)
     from ctypes import c_void_p
     from . import _lib
     out = torch.empty((cout, cin) + tuple(kernel), dtype=torch.float32, device=dw_rows.device)
-    _lib.check(_lib.load().ndet_wgrad_to_torch(c_void_p(dw_rows.data_ptr()), taps, cout, cin, c_void_p(out.data_ptr()),
+    _lib.check(_lib.load().ndet_wgrad_to_torch(c_void_p(dw_rows.data_ptr()), splits, taps, cout, cin, c_void_p(out.data_ptr()),
                                                c_void_p(torch.cuda.current_stream(dw_rows.device).cuda_stream)), "wgrad_to_torch")
     return out
 
@@ -240,25 +242,33 @@ def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pa
         splits = max(1, min(32, ksteps // 8, -(-768 // tiles)))
         m = taps * cin
         ws = torch.empty((splits * m * cout,), dtype=torch.float32, device=x.device) if splits > 1 else None
-        dw = torch.empty((m, cout), dtype=torch.float32, device=x.device)
+        keep = f16 and splits > 1 and taps <= 27       # the partials go straight to ndet_wgrad_to_torch: no reduction pass, no (m, cout) intermediate
+        dw = None if keep else torch.empty((m, cout), dtype=torch.float32, device=x.device)
         i3 = lambda v: (ctypes.c_int * 3)(*v)
         st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         if f16:
             _lib.check(_lib.load().ndet_wgrad_split_f16x2(c_void_p(x.data_ptr()), d, h, w, cin, i3(k3), i3(s3), i3(pads), c_void_p(planes.data_ptr()), cout, lrow,
                                                           splits, c_void_p(x_slot.data_ptr()), c_void_p(dy_slot.data_ptr()), c_void_p(0 if ws is None else ws.data_ptr()),
-                                                          c_void_p(dw.data_ptr()), st), "wgrad_split_f16x2")
+                                                          c_void_p(ws.data_ptr() if keep else dw.data_ptr()), int(keep), st), "wgrad_split_f16x2")
+            if keep:
+                return _to_torch_layout(ws, taps, cin, cout, kernel, splits)
         else:
             _lib.check(_lib.load().ndet_wgrad_split(c_void_p(x.data_ptr()), d, h, w, cin, i3(k3), i3(s3), i3(pads), c_void_p(planes.data_ptr()), cout, lrow,
                                                     splits, 0 if arith == "bf16" else 2, c_void_p(0 if ws is None else ws.data_ptr()),
                                                     c_void_p(dw.data_ptr()), st), "wgrad_split")
         return _to_torch_layout(dw, taps, cin, cout, kernel)
     per = max(1, min(taps, (1 << 30) // (cin * lrow * 4)))  # the kernel addresses its operand with 32-bit byte offsets: <= 1 GiB per launch
+    if f16 and per >= taps and taps <= 27 and cin % 32 == 0:
+        pk["keep_partials"] = True                          # one GEMM: its split-K partials are added by ndet_wgrad_to_torch (no reduction pass)
     parts = []
     for t0 in range(0, taps, per):
         a_all = _rows(x, k3, s3, pads, t0, min(per, taps - t0), lrow)          # rows (t, ci): x sampled at tap t of every output voxel
         if f16:
             C._tag_amax(a_all, x_slot)                                         # copies of x's elements and zeros: max |rows| <= max |x|
         parts.append(C.linear_rows(C.carry_amax(a_all, a_all.view(-1, lrow)), pk))     # (taps*Cin, Cout): the sum over the output voxels
+    kept = pk.pop("_partials", None)
+    if kept is not None:
+        return _to_torch_layout(kept[0], taps, cin, cout, kernel, kept[1])
     dw = parts[0] if len(parts) == 1 else torch.cat(parts)
     return _to_torch_layout(dw, taps, cin, cout, kernel)
 
@@ -436,13 +446,19 @@ def eligible_transposed(conv: nn.Module, x: Tensor) -> bool:
             and tuple(conv.dilation) == (1, 1, 1) and conv.groups == 1 and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0)
 
 
+def _scene(x: Tensor, b: int) -> Tensor:
+    """``x[b]``; for a batch of one as a VIEW op (squeeze): the backward of a select allocates a zero tensor of the batch's shape and copies the
+    gradient into its slice -- two passes over every 3D convolution's input gradient (measured: 9 fills + 9 copies of 26 MB per training step)."""
+    return x.squeeze(0) if x.shape[0] == 1 else x[b]
+
+
 def conv_forward(conv: nn.Module, x: Tensor) -> Tensor:
     """``conv(x)`` for a logical (B,C,...) tensor: eligible layers run on the MFMA kernels under autograd (channels-last memory in,
     channels-last memory out, logical shape unchanged); everything else goes to the module itself."""
     if torch.is_grad_enabled() and eligible_transposed(conv, x):
         outs = []
         for b in range(x.shape[0]):
-            xb = x[b].permute(1, 2, 3, 0)
+            xb = _scene(x, b).permute(1, 2, 3, 0)
             outs.append(ConvT2.apply(xb if xb.is_contiguous() else xb.contiguous(), conv.weight).permute(3, 0, 1, 2))
         y = outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
         return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1, 1)
@@ -452,7 +468,7 @@ def conv_forward(conv: nn.Module, x: Tensor) -> Tensor:
     outs = []
     if three_d:
         for b in range(x.shape[0]):                                           # one scene at a time: the kernel's depth axis is X
-            xb = x[b].permute(1, 2, 3, 0)
+            xb = _scene(x, b).permute(1, 2, 3, 0)
             y = ConvS1.apply(xb if xb.is_contiguous() else xb.contiguous(), conv.weight, conv.stride[0])
             outs.append(y.permute(3, 0, 1, 2))
         y = outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
@@ -473,7 +489,7 @@ def conv_forward_shared(convs: Sequence[nn.Module], x: Tensor):
     w = torch.cat([c.weight for c in convs], dim=0)
     outs = []
     for b in range(x.shape[0]):
-        xb = x[b].permute(1, 2, 3, 0)
+        xb = _scene(x, b).permute(1, 2, 3, 0)
         outs.append(ConvS1.apply(xb if xb.is_contiguous() else xb.contiguous(), w).permute(3, 0, 1, 2))
     y = outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
     res, o = [], 0

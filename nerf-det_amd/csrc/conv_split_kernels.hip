@@ -25,6 +25,10 @@
 
 #include "spl_common.hpp"
 
+// set per call by the weight-gradient entry points (ndet_conv_ndhwc_train, ndet_wgrad_split*): the split-K partials stay in the workspace and
+// ndet_wgrad_to_torch adds them up (same fixed order) on its way to torch's layout -- one launch and one pass over dW fewer per layer
+static thread_local int g_keep_partials = 0;
+
 // K walk of the unified tiles: fills acc (per-wave 32x32 MFMA tiles) for GEMM rows m0.. and channels n0..; returns the transposed-conv tap
 // (blockIdx.z) in ztap.  Ends behind a barrier: the LDS operand planes are free for the epilogue.
 template <int BM, int BN, int WGM, int WGN, int SCH>
@@ -1766,6 +1770,7 @@ int conv_split_launch(Conv3dParams& p, int tile, hipStream_t st, const char* fn)
     }
     if (rc != NDET_OK) return rc;
     NDET_CHECK_LAUNCH(fn);
+    if (g_keep_partials && p.splits > 1) return NDET_OK;
     return conv_splitk_reduce_launch(p, st, fn);
 }
 
@@ -1913,14 +1918,20 @@ __global__ __launch_bounds__(1024) void k_split_weights_train(const float* __res
 // The weight gradient's last step: dw_rows ((tap, ci) rows x Cout, what the GEMMs write) -> torch's (Cout, Cin, taps) layout.  The same 32 x 32 x taps
 // block through LDS as above, the other way round: 128-byte row pieces in, one contiguous run of 32 taps floats per output channel out.  (As
 // `dw.view(taps, Cin, Cout).permute(2, 1, 0).reshape(...)` this was ATen's generic strided copy: ~2.4 ms of the training step for 108 M parameters.)
-__global__ __launch_bounds__(1024) void k_wgrad_to_torch(const float* __restrict__ rows, int taps, int Cout, int Cin, float* __restrict__ out) {
+// `splits` > 1: `rows` holds that many split-K partials, taps * Cin * Cout floats apart, added here in index order (the order k_conv3d_splitk_reduce uses).
+__global__ __launch_bounds__(1024) void k_wgrad_to_torch(const float* __restrict__ rows, int splits, int taps, int Cout, int Cin, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float wt_tile[];      // [32 co][32 ci x taps + 1]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
     const int run = 32 * taps, pitch = run + 1;
     for (int item = tid; item < taps * 1024; item += 1024) {
         const int tap = item >> 10, r = (item >> 5) & 31, c = item & 31;       // r: input channel, c: output channel
-        if (co0 + c < Cout) wt_tile[c * pitch + r * taps + tap] = rows[((int64_t)tap * Cin + ci0 + r) * Cout + co0 + c];
+        if (co0 + c < Cout) {
+            const float* src = rows + ((int64_t)tap * Cin + ci0 + r) * Cout + co0 + c;
+            float v = src[0];
+            for (int sidx = 1; sidx < splits; ++sidx) v = v + src[(int64_t)sidx * taps * Cin * Cout];
+            wt_tile[c * pitch + r * taps + tap] = v;
+        }
     }
     __syncthreads();
     for (int r = wave; r < 32; r += 16) {
@@ -1931,9 +1942,9 @@ __global__ __launch_bounds__(1024) void k_wgrad_to_torch(const float* __restrict
     }
 }
 
-extern "C" int ndet_wgrad_to_torch(const float* dw_rows, int taps, int Cout, int Cin, float* dw_torch, void* stream) {
+extern "C" int ndet_wgrad_to_torch(const float* dw_rows, int splits, int taps, int Cout, int Cin, float* dw_torch, void* stream) {
     const char* fn = "ndet_wgrad_to_torch";
-    NDET_REQUIRE(dw_rows && dw_torch, NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(dw_rows && dw_torch && splits >= 1, NDET_E_INVALID, "%s: null pointer / splits < 1", fn);
     NDET_REQUIRE(taps > 0 && taps <= 27 && Cout > 0 && Cin > 0 && Cin % 32 == 0 && (Cout + 31) / 32 <= 65535, NDET_E_UNSUPPORTED, "%s: 1..27 taps, Cin %% 32 == 0", fn);
     const size_t lds = (size_t)32 * (32 * taps + 1) * sizeof(float);
     if (lds > 48 * 1024) {
@@ -1946,7 +1957,7 @@ extern "C" int ndet_wgrad_to_torch(const float* dw_rows, int taps, int Cout, int
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
     }
-    hipLaunchKernelGGL(k_wgrad_to_torch, dim3(Cin / 32, (Cout + 31) / 32), dim3(1024), lds, (hipStream_t)stream, dw_rows, taps, Cout, Cin, dw_torch);
+    hipLaunchKernelGGL(k_wgrad_to_torch, dim3(Cin / 32, (Cout + 31) / 32), dim3(1024), lds, (hipStream_t)stream, dw_rows, splits, taps, Cout, Cin, dw_torch);
     NDET_CHECK_LAUNCH(fn);
     return NDET_OK;
 }
@@ -2021,12 +2032,15 @@ extern "C" int ndet_conv_ndhwc_guarded(const float* in, const uint16_t* w_planes
 extern "C" int ndet_conv_ndhwc_train(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
                                      const int* kernel, const int* stride, const int* pad, const float* scale, const float* shift, const float* residual,
                                      int relu, int splits, int tile, const float* in_amax, const float* w_amax, float* out_amax, void* workspace,
-                                     float guard_k, float guard_tol, unsigned* guard, void* stream) {
+                                     float guard_k, float guard_tol, unsigned* guard, int keep_partials, void* stream) {
     NDET_REQUIRE(w_amax != nullptr, NDET_E_INVALID, "ndet_conv_ndhwc_train: the weight planes' amax slot is required");
+    NDET_REQUIRE(!keep_partials || (!scale && !residual && !relu && !out_amax), NDET_E_INVALID, "ndet_conv_ndhwc_train: keep_partials leaves the epilogue to ndet_wgrad_to_torch (no affine / residual / ReLU / amax)");
     NDET_REQUIRE(!guard || (guard_k >= 0.0f && guard_tol > 0.0f), NDET_E_INVALID, "ndet_conv_ndhwc_train: the guard needs guard_k >= 0 and guard_tol > 0");
     g_guard = ConvGuard{guard, guard_k, 0.0f, guard_tol, w_amax};
+    g_keep_partials = keep_partials ? 1 : 0;
     const int rc = ndet_conv_ndhwc_arith(in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, 0, scale, shift, residual, 0, relu, splits, tile, 1, in_amax, 1.0f,
                                          out_amax, workspace, stream);
+    g_keep_partials = 0;
     g_guard = ConvGuard{nullptr, 0.0f, 0.0f, 0.0f, nullptr};
     return rc;
 }
@@ -2234,7 +2248,7 @@ static int wgrad_launch(const WgradParams& g, const Conv3dParams& p, const uint1
 
 static int wgrad_split_entry(const char* fn, const float* x_ndhwc, int D, int H, int W, int Cin, const int* kernel, const int* stride, const int* pad,
                              const uint16_t* dy_planes, int Cout, int lrow, int splits, int max_order, const float* x_amax, const float* dy_amax, void* workspace,
-                             float* dw_rows, void* stream) {
+                             float* dw_rows, int keep_partials, void* stream) {
     NDET_REQUIRE(x_ndhwc && kernel && stride && pad && dy_planes && dw_rows, NDET_E_INVALID, "%s: null pointer", fn);
     NDET_REQUIRE(D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && lrow > 0 && lrow % CBK == 0, NDET_E_INVALID, "%s: bad sizes", fn);
     NDET_REQUIRE(Cin % 64 == 0, NDET_E_UNSUPPORTED, "%s: Cin=%d must be a multiple of 64", fn, Cin);
@@ -2290,6 +2304,7 @@ static int wgrad_split_entry(const char* fn, const float* x_ndhwc, int D, int H,
 #undef NDET_WGRAD_TILE
     if (rc != NDET_OK) return rc;
     NDET_CHECK_LAUNCH(fn);
+    if (keep_partials && p.splits > 1) return NDET_OK;
     return conv_splitk_reduce_launch(p, st, fn);
 }
 
@@ -2297,14 +2312,15 @@ extern "C" int ndet_wgrad_split(const float* x_ndhwc, int D, int H, int W, int C
                                 const uint16_t* dy_planes, int Cout, int lrow, int splits, int max_order, void* workspace, float* dw_rows,
                                 void* stream) {
     NDET_REQUIRE(max_order == 0 || max_order == 2, NDET_E_INVALID, "ndet_wgrad_split: max_order 0 (bf16) or 2 (bf16x3); the fp16-pair form is ndet_wgrad_split_f16x2");
-    return wgrad_split_entry("ndet_wgrad_split", x_ndhwc, D, H, W, Cin, kernel, stride, pad, dy_planes, Cout, lrow, splits, max_order, nullptr, nullptr, workspace, dw_rows, stream);
+    return wgrad_split_entry("ndet_wgrad_split", x_ndhwc, D, H, W, Cin, kernel, stride, pad, dy_planes, Cout, lrow, splits, max_order, nullptr, nullptr, workspace, dw_rows, 0, stream);
 }
 
 // The same implicit GEMM in the fp16-pair arithmetic: dy_planes from ndet_wgrad_dy_planes_f16x2 (two planes per K step, scaled by its slot), x split in
 // the kernel under the scale of x_amax, three products.
 extern "C" int ndet_wgrad_split_f16x2(const float* x_ndhwc, int D, int H, int W, int Cin, const int* kernel, const int* stride, const int* pad,
                                       const uint16_t* dy_planes, int Cout, int lrow, int splits, const float* x_amax, const float* dy_amax, void* workspace,
-                                      float* dw_rows, void* stream) {
-    return wgrad_split_entry("ndet_wgrad_split_f16x2", x_ndhwc, D, H, W, Cin, kernel, stride, pad, dy_planes, Cout, lrow, splits, 1, x_amax, dy_amax, workspace, dw_rows, stream);
+                                      float* dw_rows, int keep_partials, void* stream) {
+    return wgrad_split_entry("ndet_wgrad_split_f16x2", x_ndhwc, D, H, W, Cin, kernel, stride, pad, dy_planes, Cout, lrow, splits, 1, x_amax, dy_amax, workspace, dw_rows,
+                             keep_partials, stream);
 }
 
