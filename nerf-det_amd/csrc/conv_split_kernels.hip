@@ -1928,8 +1928,18 @@ __global__ __launch_bounds__(1024) void k_wgrad_to_torch(const float* __restrict
         const int tap = item >> 10, r = (item >> 5) & 31, c = item & 31;       // r: input channel, c: output channel
         if (co0 + c < Cout) {
             const float* src = rows + ((int64_t)tap * Cin + ci0 + r) * Cout + co0 + c;
+            const int64_t ps = (int64_t)taps * Cin * Cout;
             float v = src[0];
-            for (int sidx = 1; sidx < splits; ++sidx) v = v + src[(int64_t)sidx * taps * Cin * Cout];
+            // eight partials in flight, added in index order (a loop of load-then-add waits out one memory latency per partial: measured 28 us per
+            // launch on average against 9 + 9 for the separate reduction and layout passes)
+            for (int s0 = 1; s0 < splits; s0 += 8) {
+                float t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = s0 + k < splits ? src[(int64_t)(s0 + k) * ps] : 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (s0 + k < splits) v = v + t[k];
+            }
             wt_tile[c * pitch + r * taps + tap] = v;
         }
     }

@@ -109,7 +109,7 @@ def test_training_and_fusion_eligibility_rules():
     finally:
         conv3d.set_arithmetic(prev)
     assert conv3d.choose_tiling_split(240000, 256, 2, 100064, 0) == (100064, 1)   # direct-epilogue tiles never split K
-    assert conv3d.choose_tiling_split(2304, 256, 375)[1] > 4 and conv3d.choose_tiling_split(2304, 256, 375)[0] == 128256   # ... the 128 x 256 tile (code 128256) does
+    assert conv3d.choose_tiling_split(2304, 256, 375)[1] > 4 and conv3d.choose_tiling_split(2304, 256, 375)[0] in (128256, 129256)   # ... the 128 x 256 tile (code 128256, or its persistent form since the training sweep) does
 
 
 def test_ssim_closed_form_cases():
