@@ -482,6 +482,21 @@ int ndet_wgrad_split_f16x2(const float* x_ndhwc, int D, int H, int W, int Cin, c
 int ndet_split_weights_train(const float* w_torch, int taps, int Cout, int Cin, int arith, const float* w_amax, uint16_t* planes,
                              uint16_t* planes_adjoint, void* stream);
 
+/* BatchNorm on BATCH statistics over channels-last rows (N x C fp32, C / 4 a divisor of 1024), with the ReLU and the residual add that follow it in
+ * BasicBlock3dV2 / the up and out blocks of FastIndoorImVoxelNeck folded in (mmdet3d/models/necks/imvoxelnet.py:22-67,233-260; training mode of
+ * nn.BatchNorm3d): y = relu?((x - mean) / sqrt(var + eps) * gamma + beta (+ residual)), mean / biased var over the N rows; running_mean /
+ * running_var (may be null) updated with `momentum` (unbiased variance), save_mean / save_invstd kept for the backward.  y_amax (may be null): a
+ * zeroed amax slot that receives max |y|.  workspace: ndet_bn_workspace_floats(N, C) floats.  Three launches (partial sums, finish, apply); the
+ * partial sums are added in a fixed order.  The backward: dx = gamma invstd (g - mean(g) - xhat mean(g xhat)) with g = dy [y > 0] when relu (y = the
+ * forward's output), d_residual (may be null) = g, dgamma = sum g xhat, dbeta = sum g; dx_amax as y_amax. */
+int64_t ndet_bn_workspace_floats(int64_t N, int C);
+int ndet_bn_train_forward(const float* x, int64_t N, int C, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          float momentum, float eps, const float* residual, int relu, float* y, float* save_mean, float* save_invstd, float* y_amax,
+                          float* workspace, void* stream);
+int ndet_bn_train_backward(const float* dy, const float* x, const float* y, int64_t N, int C, const float* gamma, const float* save_mean,
+                           const float* save_invstd, int relu, float* dx, float* d_residual, float* dgamma, float* dbeta, float* dx_amax,
+                           float* workspace, void* stream);
+
 /* The weight gradient in torch's layout: dw_rows ((tap, ci) rows x Cout floats, what ndet_wgrad_split* and the staged GEMM write) ->
  * dw_torch (Cout, Cin, taps), the layout autograd hands to the optimizer for nn.Conv3d / nn.Conv2d.weight
  * (mmdet3d/models/necks/imvoxelnet.py:22-67,233-260).  32 x 32 x taps blocks through LDS, coalesced on both sides; taps <= 27, Cin % 32 == 0.

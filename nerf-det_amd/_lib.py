@@ -83,6 +83,9 @@ SIGNATURES = {
     "ndet_wgrad_dy_planes": ([_P, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_wgrad_dy_planes_f16x2": ([_P, c_int, c_int, c_int, _P, _P, _P], c_int),
     "ndet_wgrad_split_f16x2": ([_P] + [c_int] * 4 + [_P, _P, _P, _P] + [c_int] * 3 + [_P, _P, _P, _P, c_int, _P], c_int),
+    "ndet_bn_workspace_floats": ([c_int64, c_int], c_int64),
+    "ndet_bn_train_forward": ([_P, c_int64, c_int, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, _P, _P, _P], c_int),
+    "ndet_bn_train_backward": ([_P, _P, _P, c_int64, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P], c_int),
     "ndet_wgrad_to_torch": ([_P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_split_weights_train": ([_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P], c_int),
     "ndet_conv_ndhwc_train": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P], c_int),

@@ -500,3 +500,73 @@ def conv_forward_shared(convs: Sequence[nn.Module], x: Tensor):
         res.append(part)
         o += c.out_channels
     return res
+
+
+BN_KERNELS = True     # BatchNorm on batch statistics (+ ReLU, + residual) of the 3D neck on csrc/bn_kernels.hip; False: F.batch_norm + separate passes
+
+
+def bn_rows_ok(bn: nn.Module, rows: Tensor) -> bool:
+    """Training-mode BatchNorm with affine parameters over contiguous fp32 GPU rows whose width the kernels' lane layout takes."""
+    c = rows.shape[-1]
+    return (BN_KERNELS and bn.training and bn.affine and rows.is_cuda and rows.dtype == torch.float32 and rows.is_contiguous() and torch.is_grad_enabled()
+            and c % 4 == 0 and c // 4 <= 1024 and 1024 % (c // 4) == 0 and rows.numel() // c >= 2)
+
+
+def _bump_version(*tensors) -> None:
+    """The library wrote these tensors in place through raw pointers: advance their version counters as an in-place torch op would have."""
+    bump = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
+    if bump is not None:
+        bump(list(tensors), [t._version + 1 for t in tensors])
+    else:
+        for t in tensors:
+            t.add_(0)
+
+
+class BatchNormRows(torch.autograd.Function):
+    """y = relu?(batch_norm(x) (+ residual)) over (N, C) rows on batch statistics: csrc/bn_kernels.hip (three launches forward, three backward; the
+    library path is a statistics kernel, a normalise pass, a ReLU pass, an add pass, and their four backward counterparts).  In the fp16-pair mode the
+    apply passes leave max |y| / max |dx| behind for the convolutions that read them."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, residual):
+        from ctypes import c_void_p
+        from . import _lib
+        lib = _lib.load()
+        xc = x.detach()
+        n, c = xc.shape
+        res = None if residual is None else residual.detach().contiguous()
+        y = torch.empty_like(xc)
+        mean, invstd = torch.empty(c, dtype=torch.float32, device=x.device), torch.empty(c, dtype=torch.float32, device=x.device)
+        ws = torch.empty(int(lib.ndet_bn_workspace_floats(n, c)), dtype=torch.float32, device=x.device)
+        slot = C.AMAX.take(x.device) if C.train_arithmetic() == "f16x2" else None
+        p = lambda t: c_void_p(0 if t is None else t.data_ptr())
+        _lib.check(lib.ndet_bn_train_forward(p(xc), n, c, p(weight.detach()), p(bias.detach()), p(running_mean), p(running_var), float(momentum), float(eps), p(res),
+                                             int(bool(relu)), p(y), p(mean), p(invstd), p(slot), p(ws), c_void_p(torch.cuda.current_stream(x.device).cuda_stream)),
+                   "bn_train_forward")
+        if slot is not None:
+            C._tag_amax(y, slot)
+        if running_mean is not None:
+            _bump_version(running_mean, running_var)       # written through raw pointers: the eval-mode packs key on the buffers' versions (conv3d.bn_affine)
+        ctx.relu, ctx.has_res = bool(relu), residual is not None
+        ctx.save_for_backward(xc, y if relu else None, weight.detach(), mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from ctypes import c_void_p
+        from . import _lib
+        lib = _lib.load()
+        x, y, w, mean, invstd = ctx.saved_tensors
+        g = g.contiguous()
+        n, c = x.shape
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[8]) else None
+        dgamma, dbeta = torch.empty(c, dtype=torch.float32, device=x.device), torch.empty(c, dtype=torch.float32, device=x.device)
+        ws = torch.empty(int(lib.ndet_bn_workspace_floats(n, c)), dtype=torch.float32, device=x.device)
+        slot = C.AMAX.take(x.device) if C.train_arithmetic() == "f16x2" else None
+        p = lambda t: c_void_p(0 if t is None else t.data_ptr())
+        _lib.check(lib.ndet_bn_train_backward(p(g), p(x), p(y), n, c, p(w), p(mean), p(invstd), int(ctx.relu), p(dx), p(dres), p(dgamma), p(dbeta), p(slot), p(ws),
+                                              c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "bn_train_backward")
+        if slot is not None:
+            C._tag_amax(dx, slot)
+        return dx, dgamma, dbeta, None, None, None, None, None, dres

@@ -31,10 +31,9 @@ class BasicBlock3dV2(nn.Module):
     def forward(self, x):
         """Library form (training: BatchNorm on batch statistics, autograd).  On the GPU the stride-1 convolutions still run on the
         MFMA kernels, forward and backward (nerfdet_amd/conv_train.py)."""
-        out = self.relu(_bn(self.norm1, conv_forward(self.conv1, x)))
-        out = _bn(self.norm2, conv_forward(self.conv2, out))
+        out = _bn(self.norm1, conv_forward(self.conv1, x), relu=True)
         idt = _run(self.downsample, x) if self.stride != 1 else x
-        return self.relu(out + idt)
+        return _bn(self.norm2, conv_forward(self.conv2, out), relu=True, residual=idt)       # relu(norm2(.) + identity), imvoxelnet.py:60-66
 
     def forward_ndhwc(self, x):
         """x (D,H,W,C) -> (D',H',W',C'); eval-mode BN folded, ``relu(bn2(conv2(.)) + identity)`` in one epilogue."""
@@ -43,23 +42,37 @@ class BasicBlock3dV2(nn.Module):
         return conv3d_ndhwc(y, packed([self.conv2], self.norm2), residual=idt, relu=1)
 
 
-def _bn(bn: nn.BatchNorm3d, x):
-    """``bn(x)`` for a logical (B,C,D,H,W) tensor held in channels-last memory, evaluated on its (voxels, C) row view: F.batch_norm's 2D form
-    reduces over the same elements per channel (same statistics, same running-average update), and neither it nor autograd's backward
-    leaves channels-last memory -- the 5D library path returns NCDHW memory, forward and backward, and every convolution after it then
-    starts with a transposing copy."""
+def _bn(bn: nn.BatchNorm3d, x, relu: bool = False, residual=None):
+    """``relu?(bn(x) (+ residual))`` for a logical (B,C,D,H,W) tensor held in channels-last memory, evaluated on its (voxels, C) row view: the 2D
+    form reduces over the same elements per channel (same statistics, same running-average update), and neither it nor its backward leaves
+    channels-last memory -- the 5D library path returns NCDHW memory, forward and backward, and every convolution after it then starts with a
+    transposing copy.  In training on the GPU the whole expression is csrc/bn_kernels.hip (conv_train.BatchNormRows)."""
+    def tail(y):
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
     rows = x.permute(0, 2, 3, 4, 1) if (x.is_cuda and x.dim() == 5) else None
     if rows is None or not rows.is_contiguous():
-        return bn(x)
+        return tail(bn(x))
     factor = 0.0 if bn.momentum is None else bn.momentum
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
         if bn.momentum is None:
             factor = 1.0 / float(bn.num_batches_tracked)
     training = bn.training or (bn.running_mean is None and bn.running_var is None)
-    y = F.batch_norm(rows.reshape(-1, x.shape[1]), bn.running_mean if (not bn.training or bn.track_running_stats) else None,
+    from .conv_train import BatchNormRows, bn_rows_ok
+    flat = rows.reshape(-1, x.shape[1])
+    res_rows = None
+    if residual is not None:
+        rr = residual.permute(0, 2, 3, 4, 1)
+        res_rows = rr.reshape(-1, x.shape[1]) if rr.is_contiguous() else None
+    if bn_rows_ok(bn, flat) and (residual is None or res_rows is not None):
+        track = bn.training and bn.track_running_stats
+        y = BatchNormRows.apply(flat, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None, factor, bn.eps, relu, res_rows)
+        return carry_amax(y, y.view(rows.shape).permute(0, 4, 1, 2, 3))
+    y = F.batch_norm(flat, bn.running_mean if (not bn.training or bn.track_running_stats) else None,
                      bn.running_var if (not bn.training or bn.track_running_stats) else None, bn.weight, bn.bias, training, factor, bn.eps)
-    return y.view(rows.shape).permute(0, 4, 1, 2, 3)
+    return tail(y.view(rows.shape).permute(0, 4, 1, 2, 3))
 
 
 def _conv_bn_relu(cin, cout):
@@ -67,9 +80,20 @@ def _conv_bn_relu(cin, cout):
 
 
 def _run(seq: nn.Sequential, x):
-    """``seq(x)`` with its convolutions routed through :func:`conv_forward`."""
-    for m in seq:
-        x = conv_forward(m, x) if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d)) else _bn(m, x) if isinstance(m, nn.BatchNorm3d) else m(x)
+    """``seq(x)`` with its convolutions routed through :func:`conv_forward` and every BatchNorm + ReLU pair through one :func:`_bn`."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d)):
+            x = conv_forward(m, x)
+        elif isinstance(m, nn.BatchNorm3d):
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = _bn(m, x, relu=fuse)
+            i += int(fuse)
+        else:
+            x = m(x)
+        i += 1
     return x
 
 

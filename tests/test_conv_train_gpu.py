@@ -229,3 +229,39 @@ def test_both_weight_packs_in_one_launch(device, train_arith, cout, cin, kernel)
         assert torch.equal(got.view(torch.float16), want)
     from nerfdet_amd.conv3d import amax_value
     assert amax_value(slot) == float(w.abs().max())
+
+
+@pytest.mark.parametrize("n,c,relu,with_res", [(25600, 256, True, False), (3200, 512, True, True), (400, 1024, False, False), (777, 128, True, True), (50, 64, False, True),
+                                               (100000, 32, True, False)])
+def test_batch_norm_rows_forward_backward_vs_fp64(device, n, c, relu, with_res):
+    """csrc/bn_kernels.hip (BatchNorm on batch statistics + ReLU + residual over channels-last rows, mmdet3d/models/necks/imvoxelnet.py:22-67,233-260)
+    against an fp64 evaluation of relu(F.batch_norm(x) + residual): output, input / residual / affine gradients, running statistics; and not
+    further from it than the library's fp32 path on the same tensors."""
+    from nerfdet_amd.conv_train import BatchNormRows
+    torch.manual_seed(n + c)
+    x = torch.randn(n, c) * 1.7 + torch.linspace(-3, 3, c)          # per-channel means away from zero
+    res = torch.randn(n, c) if with_res else None
+    w, b = torch.rand(c) + 0.5, torch.randn(c) * 0.1
+    gy = torch.randn(n, c)
+    mom, eps = 0.1, 1e-5
+
+    def run(dtype, dev, ours):
+        xs, ws, bs = (t.to(dev, dtype).requires_grad_(True) for t in (x, w, b))
+        rs = None if res is None else res.to(dev, dtype).requires_grad_(True)
+        rm, rv = torch.zeros(c, device=dev, dtype=dtype), torch.ones(c, device=dev, dtype=dtype)
+        if ours:
+            y = BatchNormRows.apply(xs, ws, bs, rm, rv, mom, eps, relu, rs)
+        else:
+            y = F.batch_norm(xs, rm, rv, ws, bs, True, mom, eps)
+            y = y if rs is None else y + rs
+            y = torch.relu(y) if relu else y
+        (y * gy.to(dev, dtype)).sum().backward()
+        out = [y.detach(), xs.grad, ws.grad, bs.grad, rm, rv] + ([rs.grad] if rs is not None else [])
+        return [t.double().cpu() for t in out]
+    exact = run(torch.float64, "cpu", False)
+    lib = run(torch.float32, device, False)
+    ours = run(torch.float32, device, True)
+    names = ["y", "dx", "dgamma", "dbeta", "running_mean", "running_var", "dres"]
+    for name, e, l, o in zip(names, exact, lib, ours):
+        err_o, err_l = _rel(o, e), _rel(l, e)
+        assert err_o <= max(3e-6, 2.0 * err_l), (name, err_o, err_l)
