@@ -36,7 +36,7 @@ def _raw_pack(w_taps_co_ci: Tensor, kernel: Sequence[int], stride: int = 1, pads
 
 
 _STEP_SLOTS = {}      # (weight address, version) -> amax slot, filled by prepare_step for ONE step (cleared by the next call)
-_STEP_PARAMS = {}     # id(module) -> its trainable convolution weights on the GPU
+_STEP_PARAMS = {}     # id(module) -> its convolution modules
 
 
 def prepare_step(module: nn.Module) -> int:
@@ -46,10 +46,10 @@ def prepare_step(module: nn.Module) -> int:
     _STEP_SLOTS.clear()
     if C.train_arithmetic() != "f16x2":
         return 0
-    ws = _STEP_PARAMS.get(id(module))
-    if ws is None:
-        ws = _STEP_PARAMS[id(module)] = [m.weight for m in module.modules() if isinstance(m, (nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d))
-                                         and m.weight.requires_grad and m.weight.is_cuda and m.weight.dtype == torch.float32]
+    mods = _STEP_PARAMS.get(id(module))
+    if mods is None:      # the convolution MODULES are cached (a stable list); their weights are read off them every step (.to() / load_state_dict may replace them)
+        mods = _STEP_PARAMS[id(module)] = [m for m in module.modules() if isinstance(m, (nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d))]
+    ws = [m.weight for m in mods if m.weight.requires_grad and m.weight.is_cuda and m.weight.dtype == torch.float32]
     if not ws:
         return 0
     with torch.no_grad():
