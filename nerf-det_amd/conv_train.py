@@ -157,6 +157,7 @@ def eligible(conv: nn.Module, x: Tensor) -> bool:
 FUSED_DY_PLANES = True    # dy goes to the weight-gradient GEMM's bf16 planes in one pass (k_wgrad_dy_planes) instead of transpose + split
 IMPLICIT_WGRAD = True     # multi-tap weight gradients on large grids read x in place (k_wgrad_split); False: always the staged form
                           # (tap copies by k_wgrad_rows + one GEMM)
+IMPLICIT_MIN_TAPS = 9     # fewer taps: the staged form (its GEMM runs on the faster tiles and the tap copies are 1 - 8 x the input)
 
 
 def _rows(x: Tensor, k3, stride3, pads, t0: int, n_taps: int, lrow: int) -> Tensor:
@@ -226,7 +227,7 @@ def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pa
         pk = dict(w=grows, scale=None, shift=None, cout=cout, cin=lrow, ksize=1, stride=1, transposed=False, kernel=(1, 1), strides=(1, 1),
                   pads=(0, 0), ndim=2, arith="bf16x3")
     if implicit is None:
-        implicit = IMPLICIT_WGRAD and taps >= 9 and lo >= 16384
+        implicit = IMPLICIT_WGRAD and taps >= IMPLICIT_MIN_TAPS and lo >= 16384
     if implicit and arith in ("bf16x3", "bf16", "f16x2") and cin % 64 == 0:
         # multi-tap layers on large grids: x read in place (csrc/conv_split_kernels.hip::k_wgrad_split), no tap copies -- there the staged
         # form writes and re-reads taps x the input (707 MB for a 3x3x3 layer at 40x40x16x256); on small grids and 1x1 layers the staged

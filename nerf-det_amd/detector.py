@@ -114,15 +114,15 @@ class nerfdet(BaseDetector):
         assert ray_batch is not None and self.nerf_density and self.nerf_mode == "image", \
             "effective contract of the reference: use_ray=True, nerf_density=True, nerf_mode='image' (SURVEY.md 0.2)"
         trace.mark("begin")
-        begun = None
+        draws = None
         if mode == "train":
-            from .rays import begin_selection, finish_selection
-            begun = begin_selection(ray_batch)       # needs one host sync: taken before anything is queued
+            from .rays import begin_selection, collect_draw, submit_draw
+            begun = begin_selection(ray_batch)       # (reads one count back unless the loader supplied depth_rays)
+            # the reference's host-side ray draw (a numpy permutation of every ray with depth: ~5 ms) runs on a worker thread while this one
+            # queues the backbone; one draw per scene, in scene order, as render_ray.py:398 consumes its RandomState
+            draws = [submit_draw(begun, self.N_rand) for _ in img_metas]
         x, batch, stride = self.extract_2d(img)
         trace.mark("backbone_fpn")
-        # the reference's host-side ray draw (a numpy permutation of every ray with depth: milliseconds) runs while the GPU works through
-        # the backbone queue; one draw per scene, in scene order, as render_ray.py:398 consumes its RandomState
-        picks = [finish_selection(begun, self.N_rand) for _ in img_metas] if begun is not None else None
         # per-scene constants: host arithmetic while the GPU works through the backbone queue, asynchronous upload
         geoms = None
         if not torch.is_grad_enabled():
@@ -142,7 +142,7 @@ class nerfdet(BaseDetector):
                 rgb_preds.append(render_rays(ray_batch, None, None, out["feature_2d"], dn, self.aabb, self.near_far_range,
                                              self.N_samples, self.N_rand, self.nerf_mlp, img_meta, None, self.nerf_mode,
                                              self.nerf_sample_view, is_train=(mode == "train"),
-                                             render_testing=self.render_testing, selection=None if picks is None else picks[b]))
+                                             render_testing=self.render_testing, selection=None if draws is None else collect_draw(draws[b])))
             else:
                 rgb_preds.append(None)  # render_ray.py:518-519
             volumes.append(out["volume"])

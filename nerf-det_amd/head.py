@@ -38,7 +38,7 @@ class Detections(list):
 
 def compute_centerness(t):
     """imvoxel_head_v2.py:558-566: sqrt of the product of min/max ratios per axis."""
-    x, y, z = t[..., [0, 1]], t[..., [2, 3]], t[..., [4, 5]]
+    x, y, z = t[..., 0:2], t[..., 2:4], t[..., 4:6]      # slices: a list index builds its index tensor on the host and copies it over (a blocking pageable copy each)
     c = x.min(dim=-1)[0] / x.max(dim=-1)[0] * y.min(dim=-1)[0] / y.max(dim=-1)[0] * z.min(dim=-1)[0] / z.max(dim=-1)[0]
     return torch.sqrt(c)
 

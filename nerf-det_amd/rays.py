@@ -278,16 +278,51 @@ def begin_selection(ray_batch):
     return kept, int(kept.numel()), rays.device
 
 
-def finish_selection(begun, n_rand):
-    """Second half: ``N_rand`` of those rays drawn without replacement from the module-global RandomState (the reference's stream and call,
-    render_ray.py:20,398 -- a permutation of all kept rays on the host, milliseconds: the detector runs it while the GPU works through
-    the backbone).  Returns indices into the flattened ray list (device tensor)."""
+def _draw(n, n_rand):
+    return rng.choice(n, size=(n_rand,), replace=False)
+
+
+_DRAW_WORKER = None
+THREADED_DRAW = False     # True: the permutation runs on a worker thread beside the backbone's launches.  Measured (tools/bench_train.py --threaded-draw,
+                          # same box, alternating): no difference while the host runs ahead of the device (38.2 vs 38.3 ms per step), and 2 - 4 ms
+                          # WORSE when it does not (host read every step: 47.0 - 49.8 vs 45.0 - 45.7 ms) -- the hand-over between the threads costs more
+                          # than the 5 ms it hides behind launches that are themselves host-bound there
+
+
+def submit_draw(begun, n_rand):
+    """Start the host half of the ray draw on a worker thread: ``RandomState.choice(n, N_rand, replace=False)`` is a full Fisher-Yates shuffle of
+    all n rays with depth (660 000 at the configs' sizes: ~5 ms) whatever N_rand is, and the reference's RNG stream (render_ray.py:20,398) leaves no
+    way around it.  With THREADED_DRAW numpy shuffles on a worker (GIL released) while the backbone's launches go out -- ONE worker, submissions in
+    call order: the module-global RandomState is consumed in the same order as by direct calls; by default the draw runs right here (see
+    THREADED_DRAW for the measurement).  Returns a handle for :func:`collect_draw`."""
+    global _DRAW_WORKER
     kept, n, dev = begun
-    draw = torch.from_numpy(rng.choice(n, size=(n_rand,), replace=False))
+    if not THREADED_DRAW:
+        from concurrent.futures import Future
+        done = Future()
+        done.set_result(_draw(n, n_rand))
+        return kept, dev, done
+    if _DRAW_WORKER is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _DRAW_WORKER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ndet-ray-draw")
+    return kept, dev, _DRAW_WORKER.submit(_draw, n, n_rand)
+
+
+def collect_draw(handle):
+    """Second half of :func:`submit_draw`: wait for the draw, upload it (pinned staging), map it through the rays-with-depth indices."""
+    kept, dev, fut = handle
+    draw = torch.from_numpy(fut.result())
     if torch.device(dev).type == "cuda":
         from .ops import _upload_async
         draw = _upload_async(draw, dev)           # pinned staging: a pageable copy here would wait for the queued backbone to drain
     return draw if kept is None else kept[draw]
+
+
+def finish_selection(begun, n_rand):
+    """Second half: ``N_rand`` of those rays drawn without replacement from the module-global RandomState (the reference's stream and call,
+    render_ray.py:20,398 -- a permutation of all kept rays on the host, milliseconds).  Returns indices into the flattened ray list (device
+    tensor).  The detector uses :func:`submit_draw` / :func:`collect_draw` instead, which run the permutation beside the backbone's launches."""
+    return collect_draw(submit_draw(begun, n_rand))
 
 
 def render_rays(ray_batch, mean_volume, cov_volume, features_2D, img, aabb, near_far_range, N_samples, N_rand=4096, nerf_mlp=None,

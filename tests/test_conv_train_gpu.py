@@ -265,3 +265,29 @@ def test_batch_norm_rows_forward_backward_vs_fp64(device, n, c, relu, with_res):
     for name, e, l, o in zip(names, exact, lib, ours):
         err_o, err_l = _rel(o, e), _rel(l, e)
         assert err_o <= max(3e-6, 2.0 * err_l), (name, err_o, err_l)
+
+
+def test_prepare_step_hands_every_convolution_weight_its_maximum(device, train_arith):
+    """conv_train.prepare_step: max |w| of all trainable convolution weights in two launches; _split_both must find the slot (no per-tensor pass)
+    and the slot must hold the tensor's maximum.  A weight it has not seen (another module, a concatenated head weight) falls back to its own pass."""
+    from torch import nn
+    from nerfdet_amd import conv_train
+    from nerfdet_amd.conv3d import amax_value
+    torch.manual_seed(5)
+    net = nn.Sequential(nn.Conv3d(32, 64, 3, 1, 1), nn.Conv2d(64, 32, 1), nn.ConvTranspose3d(64, 32, 2, 2), nn.Linear(8, 8)).to(device)
+    net[1].weight.requires_grad_(False)                       # frozen layers are not prepared
+    n = conv_train.prepare_step(net)
+    if train_arith != "f16x2":
+        assert n == 0 and not conv_train._STEP_SLOTS
+        return
+    assert n == 2
+    for m in (net[0], net[2]):
+        slot = conv_train._STEP_SLOTS[(m.weight.data_ptr(), m.weight._version)]
+        assert amax_value(slot) == float(m.weight.abs().max())
+    _, _, slot = conv_train._split_both(net[0].weight.detach(), 27, "f16x2", False)
+    assert slot.data_ptr() == conv_train._STEP_SLOTS[(net[0].weight.data_ptr(), net[0].weight._version)].data_ptr()
+    with torch.no_grad():
+        net[0].weight.mul_(2.0)                               # the optimizer moved it: the old slot no longer applies
+    _, _, slot2 = conv_train._split_both(net[0].weight.detach(), 27, "f16x2", False)
+    assert slot2.data_ptr() != slot.data_ptr() and amax_value(slot2) == float(net[0].weight.abs().max())
+    conv_train.prepare_step(net)

@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--views", type=int, default=40)
     ap.add_argument("--lazy-log", type=int, default=1, help="1: a step's logged scalars are read from pinned memory after the next step has been queued "
                                                             "(train.StepLog); 0: host floats at the end of every step (one device drain per step)")
+    ap.add_argument("--implicit-min-taps", type=int, default=None, help=argparse.SUPPRESS)      # measurement: conv_train.IMPLICIT_MIN_TAPS
+    ap.add_argument("--threaded-draw", type=int, default=0, help=argparse.SUPPRESS)             # measurement: rays.THREADED_DRAW
     ap.add_argument("--train-f16x2", type=int, default=1, help="0: the training convolutions on the six-product bf16x3 kernels")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -102,6 +104,10 @@ def main():
     if args.arith:
         C3.set_arithmetic(args.arith)
     C3.TRAIN_F16X2 = bool(args.train_f16x2)
+    rays.THREADED_DRAW = bool(args.threaded_draw)
+    if args.implicit_min_taps is not None:
+        import nerfdet_amd.conv_train as CT
+        CT.IMPLICIT_MIN_TAPS = args.implicit_min_taps
     torch.manual_seed(0)
     det = build_nerfdet(50, depth_supervise=bool(args.depth_supervise))
     with torch.no_grad():
