@@ -9,6 +9,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import NDET_LAYOUT_CN, NDET_LAYOUT_NC, check
+from ._lib import raw_stream
 
 
 def _ptr(t):
@@ -16,7 +17,7 @@ def _ptr(t):
 
 
 def _stream(t):
-    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return c_void_p(raw_stream(t.device))
 
 
 def _dense_nhwc(t):

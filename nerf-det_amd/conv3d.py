@@ -17,6 +17,7 @@ from torch import nn
 from . import _lib, trace
 from ._lib import check
 from .conv_tuning import TUNED, TUNED_BF16, TUNED_F16, TUNED_SPLIT
+from ._lib import raw_stream
 
 # Arithmetic of the convolution kernels: "bf16x3" = fp32 operands split exactly into three bf16 terms, six bf16-MFMA
 # products accumulated in fp32 (csrc/conv_split_kernels.hip; fp32-level error, 16x the MFMA rate per product);
@@ -66,7 +67,7 @@ class _AmaxSlots:
         self.pools = {}
 
     def take(self, device) -> torch.Tensor:
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        key = (device, raw_stream(device))
         pool = self.pools.get(key)
         if pool is None or pool[1] + self.WIDTH > pool[0].numel():
             pool = self.pools[key] = [torch.zeros(4096 * self.WIDTH, dtype=torch.float32, device=device), 0]
@@ -76,7 +77,7 @@ class _AmaxSlots:
 
     def take_many(self, device, n: int) -> torch.Tensor:
         """``n`` consecutive zeroed slots as one (n, WIDTH) tensor (row i is a slot)."""
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        key = (device, raw_stream(device))
         pool = self.pools.get(key)
         if pool is None or pool[1] + n * self.WIDTH > pool[0].numel():
             pool = self.pools[key] = [torch.zeros(max(4096, n) * self.WIDTH, dtype=torch.float32, device=device), 0]
@@ -86,7 +87,7 @@ class _AmaxSlots:
 
     def fresh(self, device):
         """Drop the current stream's pool: the next slot comes from a new zero fill (graph capture: the fill must be part of the graph)."""
-        self.pools.pop((device, torch.cuda.current_stream(device).cuda_stream), None)
+        self.pools.pop((device, raw_stream(device)), None)
 
 
 AMAX = _AmaxSlots()
@@ -171,7 +172,7 @@ def amax_of(x: torch.Tensor) -> torch.Tensor:
     if slot is None:
         amax_fallbacks += 1
         slot = AMAX.take(x.device)
-        st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        st = c_void_p(raw_stream(x.device))
         check(_lib.load().ndet_amax_f32(_ptr(x), x.numel(), _ptr(slot), st), "amax_f32")
         _tag_amax(x, slot, produced=False)
     return slot
@@ -193,7 +194,7 @@ def guard_word(device) -> Optional[torch.Tensor]:
     """The guard word (int32, on the device) of the current stream, or None when the guard is off."""
     if not GUARD_ENABLED:
         return None
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, raw_stream(device))
     w = _GUARD_WORDS.get(key)
     if w is None:
         w = _GUARD_WORDS[key] = torch.zeros(1, dtype=torch.int32, device=device)
@@ -318,7 +319,7 @@ def split_planes(pk: dict) -> torch.Tensor:
         if cin % 32:
             raise ValueError(f"conv_ndhwc_split: Cin={cin} must be a multiple of 32")
         planes = torch.empty((taps, cin // 32, 3, cout, 32), dtype=torch.int16, device=w.device)
-        st = c_void_p(torch.cuda.current_stream(w.device).cuda_stream)
+        st = c_void_p(raw_stream(w.device))
         check(_lib.load().ndet_split_weights_bf16x3(_ptr(w), taps, cout, cin, _ptr(planes), st), "split_weights_bf16x3")
         pk["w_split"] = planes
     return planes
@@ -344,7 +345,7 @@ def split_planes_f16(pk: dict):
             raise ValueError(f"conv_ndhwc_arith: Cin={cin} must be a multiple of 32")
         scale = f16_weight_scale(float(w.abs().max()))
         planes = torch.empty((taps, cin // 32, 2, cout, 32), dtype=torch.int16, device=w.device)
-        st = c_void_p(torch.cuda.current_stream(w.device).cuda_stream)
+        st = c_void_p(raw_stream(w.device))
         check(_lib.load().ndet_split_weights_f16x2(_ptr(w), taps, cout, cin, scale, _ptr(planes), st), "split_weights_f16x2")
         hit = pk["w_f16"] = (planes, 1.0 / scale)
     return hit
@@ -375,7 +376,7 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
     tile = {64: 100064, 128: 100128, 12864: 112864}[base] if (base in (64, 128, 12864) and direct_ok and DIRECT_EPILOGUE) else base
     ws = torch.empty((m * pk["cout"] * splits * 4,), dtype=torch.uint8, device=x.device) if splits > 1 else None
     i3 = lambda v: (ctypes.c_int * 3)(*v)
-    st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    st = c_void_p(raw_stream(x.device))
     lib = _lib.load()
     d, h, w = dims
     nbytes = 4 * (x.numel() + pk["w"].numel() + out.numel() + (0 if residual is None else residual.numel()))
@@ -562,7 +563,7 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
     ws = None
     if splits > 1:
         ws = torch.empty((int(lib.ndet_conv3d_workspace_bytes(d, h, w, cin, cout, k, s, splits)),), dtype=torch.uint8, device=x.device)
-    st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    st = c_void_p(raw_stream(x.device))
     _launch(flops, lambda: check(lib.ndet_conv3d_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), d, h, w, cin, cout, k, s, int(tr), _ptr(pk["scale"]),
                                                        _ptr(pk["shift"]), _ptr(residual), relu, splits, tile, _ptr(ws), st), "conv3d_ndhwc"), "f32", tile,
             4 * (x.numel() + pk["w"].numel() + out.numel() + (0 if residual is None else residual.numel())))
@@ -593,7 +594,7 @@ def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = No
     tile, splits = choose_tiling(m, cout, kh * kw * (cin // 32), tile, splits)
     ws = torch.empty((m * cout * splits * 4,), dtype=torch.uint8, device=x.device) if splits > 1 else None
     i3 = lambda a, b, c: (ctypes.c_int * 3)(a, b, c)
-    st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    st = c_void_p(raw_stream(x.device))
     lib = _lib.load()
     _launch(2 * m * cout * cin * kh * kw,
             lambda: check(lib.ndet_conv_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), n, h, w, cin, cout, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw),
@@ -628,7 +629,7 @@ def conv2d_chain_nhwc(x: torch.Tensor, pk: dict, pk3: dict, residual: Optional[t
         assert tuple(residual.shape) == tuple(out.shape) and residual.is_contiguous(), (tuple(residual.shape), tuple(out.shape))
     m = n * oh * ow
     i3 = lambda a, b, c: (ctypes.c_int * 3)(a, b, c)
-    st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    st = c_void_p(raw_stream(x.device))
     lib = _lib.load()
     flops = 2 * m * mid * (cin * kh * kw + cout)
     nbytes = 4 * (x.numel() + pk["w"].numel() + pk3["w"].numel() + out.numel() + (0 if residual is None else residual.numel()))
@@ -687,7 +688,7 @@ def conv2d_bottleneck_nhwc(x: torch.Tensor, pk1: dict, pk2: dict, pk3: dict, pkd
     cout = pk3["cout"]
     out = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    st = c_void_p(raw_stream(x.device))
     (p1, i1), (p2, i2), (p3, i3) = split_planes_f16(pk1), split_planes_f16(pk2), split_planes_f16(pk3)
     pd, idd = split_planes_f16(pkd) if pkd is not None else (None, 1.0)
     in_amax = amax_of(x)
@@ -717,7 +718,7 @@ def bn_relu_maxpool_nhwc(x: torch.Tensor, bn: nn.BatchNorm2d) -> torch.Tensor:
     n, h, w, c = x.shape
     scale, shift = bn_affine(bn)
     out = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
-    st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    st = c_void_p(raw_stream(x.device))
     check(_lib.load().ndet_bn_relu_maxpool_nhwc(_ptr(x), _ptr(scale), _ptr(shift), n, h, w, c, _ptr(out), st), "bn_relu_maxpool_nhwc")
     return out
 
@@ -739,7 +740,7 @@ def stem_conv_bn_relu_maxpool(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm
     stamp = (conv.weight.data_ptr(), conv.weight._version, f16)
     hit = store.get("stem")
     lib = _lib.load()
-    st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    st = c_void_p(raw_stream(x.device))
     if hit is None or hit[0] != stamp:
         wf = conv.weight.detach().float().contiguous()
         if f16:

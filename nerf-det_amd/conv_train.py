@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from . import conv3d as C
+from ._lib import raw_stream
 
 Tensor = torch.Tensor
 
@@ -72,7 +73,7 @@ def _split_both(w: Tensor, taps: int, arith: str, want_adjoint: bool):
     planes = torch.empty((taps, cin // 32, npl, cout, 32), dtype=torch.int16, device=w.device)
     adj = torch.empty((taps, (cout + 31) // 32, npl, cin, 32), dtype=torch.int16, device=w.device) if want_adjoint else None
     wc = w.contiguous()
-    st = c_void_p(torch.cuda.current_stream(w.device).cuda_stream)
+    st = c_void_p(raw_stream(w.device))
     slot = None
     if arith == "f16x2":
         slot = _STEP_SLOTS.get((w.data_ptr(), w._version))
@@ -126,7 +127,7 @@ def _train_pack(w: Tensor, kernel, adjoint: bool, stride: int = 1, pads=None, wa
     planes = torch.empty((taps, ki // 32, 3, no, 32), dtype=torch.int16, device=w.device)
     wc = w.contiguous()
     _lib.check(_lib.load().ndet_split_weights_bf16x3_torch(c_void_p(wc.data_ptr()), taps, cout, cin, int(adjoint), c_void_p(planes.data_ptr()),
-                                                           c_void_p(torch.cuda.current_stream(w.device).cuda_stream)), "split_weights_torch")
+                                                           c_void_p(raw_stream(w.device))), "split_weights_torch")
     return _plane_pack(w, planes, None, "bf16x3", kernel, adjoint, stride, pads)
 
 
@@ -169,7 +170,7 @@ def _rows(x: Tensor, k3, stride3, pads, t0: int, n_taps: int, lrow: int) -> Tens
     out = torch.empty((n_taps, c, lrow), dtype=torch.float32, device=x.device)
     i3 = lambda v: (ctypes.c_int * 3)(*v)
     _lib.check(_lib.load().ndet_wgrad_rows(c_void_p(x.data_ptr()), d, h, w, c, i3(k3), i3(stride3), i3(pads), t0, n_taps, lrow,
-                                           c_void_p(out.data_ptr()), c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "wgrad_rows")
+                                           c_void_p(out.data_ptr()), c_void_p(raw_stream(x.device))), "wgrad_rows")
     return out
 
 
@@ -183,7 +184,7 @@ def _to_torch_layout(dw_rows: Tensor, taps: int, cin: int, cout: int, kernel, sp
     from . import _lib
     out = torch.empty((cout, cin) + tuple(kernel), dtype=torch.float32, device=dw_rows.device)
     _lib.check(_lib.load().ndet_wgrad_to_torch(c_void_p(dw_rows.data_ptr()), splits, taps, cout, cin, c_void_p(out.data_ptr()),
-                                               c_void_p(torch.cuda.current_stream(dw_rows.device).cuda_stream)), "wgrad_to_torch")
+                                               c_void_p(raw_stream(dw_rows.device))), "wgrad_to_torch")
     return out
 
 
@@ -209,7 +210,7 @@ def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pa
     if FUSED_DY_PLANES and arith in ("bf16x3", "bf16", "f16x2"):
         from ctypes import c_void_p
         from . import _lib
-        st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        st = c_void_p(raw_stream(x.device))
         planes = torch.empty((1, lrow // 32, 2 if f16 else 3, cout, 32), dtype=torch.int16, device=x.device)     # one pass: transpose + split
         if f16:
             _lib.check(_lib.load().ndet_wgrad_dy_planes_f16x2(c_void_p(g.data_ptr()), lo, cout, lrow, c_void_p(dy_slot.data_ptr()), c_void_p(planes.data_ptr()), st),
@@ -246,7 +247,7 @@ def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pa
         keep = f16 and splits > 1 and taps <= 27       # the partials go straight to ndet_wgrad_to_torch: no reduction pass, no (m, cout) intermediate
         dw = None if keep else torch.empty((m, cout), dtype=torch.float32, device=x.device)
         i3 = lambda v: (ctypes.c_int * 3)(*v)
-        st = c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        st = c_void_p(raw_stream(x.device))
         if f16:
             _lib.check(_lib.load().ndet_wgrad_split_f16x2(c_void_p(x.data_ptr()), d, h, w, cin, i3(k3), i3(s3), i3(pads), c_void_p(planes.data_ptr()), cout, lrow,
                                                           splits, c_void_p(x_slot.data_ptr()), c_void_p(dy_slot.data_ptr()), c_void_p(0 if ws is None else ws.data_ptr()),
@@ -374,12 +375,12 @@ class ConvAffineAct(torch.autograd.Function):
             _lib.check(_lib.load().ndet_relu_affine_bwd_amax(c_void_p(g.data_ptr()), c_void_p(y.data_ptr() if ctx.relu else 0), c_void_p(scale.data_ptr()),
                                                              g.numel() // g.shape[-1], g.shape[-1], int(ctx.relu), c_void_p(d_res.data_ptr() if want_res else 0),
                                                              c_void_p(gs.data_ptr()), c_void_p(slot.data_ptr()),
-                                                             c_void_p(torch.cuda.current_stream(g.device).cuda_stream)), "relu_affine_bwd_amax")
+                                                             c_void_p(raw_stream(g.device))), "relu_affine_bwd_amax")
             C._tag_amax(gs, slot)
         else:
             _lib.check(_lib.load().ndet_relu_affine_bwd(c_void_p(g.data_ptr()), c_void_p(y.data_ptr() if ctx.relu else 0), c_void_p(scale.data_ptr()),
                                                         g.numel() // g.shape[-1], g.shape[-1], int(ctx.relu), c_void_p(d_res.data_ptr() if want_res else 0),
-                                                        c_void_p(gs.data_ptr()), c_void_p(torch.cuda.current_stream(g.device).cuda_stream)), "relu_affine_bwd")
+                                                        c_void_p(gs.data_ptr()), c_void_p(raw_stream(g.device))), "relu_affine_bwd")
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if ctx.stride == 1:
@@ -542,7 +543,7 @@ class BatchNormRows(torch.autograd.Function):
         slot = C.AMAX.take(x.device) if C.train_arithmetic() == "f16x2" else None
         p = lambda t: c_void_p(0 if t is None else t.data_ptr())
         _lib.check(lib.ndet_bn_train_forward(p(xc), n, c, p(weight.detach()), p(bias.detach()), p(running_mean), p(running_var), float(momentum), float(eps), p(res),
-                                             int(bool(relu)), p(y), p(mean), p(invstd), p(slot), p(ws), c_void_p(torch.cuda.current_stream(x.device).cuda_stream)),
+                                             int(bool(relu)), p(y), p(mean), p(invstd), p(slot), p(ws), c_void_p(raw_stream(x.device))),
                    "bn_train_forward")
         if slot is not None:
             C._tag_amax(y, slot)
@@ -567,7 +568,7 @@ class BatchNormRows(torch.autograd.Function):
         slot = C.AMAX.take(x.device) if C.train_arithmetic() == "f16x2" else None
         p = lambda t: c_void_p(0 if t is None else t.data_ptr())
         _lib.check(lib.ndet_bn_train_backward(p(g), p(x), p(y), n, c, p(w), p(mean), p(invstd), int(ctx.relu), p(dx), p(dres), p(dgamma), p(dbeta), p(slot), p(ws),
-                                              c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "bn_train_backward")
+                                              c_void_p(raw_stream(x.device))), "bn_train_backward")
         if slot is not None:
             C._tag_amax(dx, slot)
         return dx, dgamma, dbeta, None, None, None, None, None, dres

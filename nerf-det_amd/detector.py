@@ -114,15 +114,19 @@ class nerfdet(BaseDetector):
         assert ray_batch is not None and self.nerf_density and self.nerf_mode == "image", \
             "effective contract of the reference: use_ray=True, nerf_density=True, nerf_mode='image' (SURVEY.md 0.2)"
         trace.mark("begin")
-        draws = None
+        draws = begun = None
         if mode == "train":
+            from . import rays
             from .rays import begin_selection, collect_draw, submit_draw
             begun = begin_selection(ray_batch)       # (reads one count back unless the loader supplied depth_rays)
-            # the reference's host-side ray draw (a numpy permutation of every ray with depth: ~5 ms) runs on a worker thread while this one
-            # queues the backbone; one draw per scene, in scene order, as render_ray.py:398 consumes its RandomState
-            draws = [submit_draw(begun, self.N_rand) for _ in img_metas]
+            if begun is not None and rays.THREADED_DRAW:      # the permutation on a worker thread beside the backbone's launches
+                draws = [submit_draw(begun, self.N_rand) for _ in img_metas]
         x, batch, stride = self.extract_2d(img)
         trace.mark("backbone_fpn")
+        if begun is not None and draws is None:
+            # the reference's host-side ray draw (a numpy permutation of every ray with depth: ~5 ms) once the backbone is queued: the device works
+            # through that queue meanwhile; one draw per scene, in scene order, as render_ray.py:398 consumes its RandomState
+            draws = [submit_draw(begun, self.N_rand) for _ in img_metas]
         # per-scene constants: host arithmetic while the GPU works through the backbone queue, asynchronous upload
         geoms = None
         if not torch.is_grad_enabled():

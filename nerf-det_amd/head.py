@@ -17,6 +17,7 @@ from . import ops
 from .conv3d import carry_amax, conv3d_ndhwc, guard_tripped, guard_word, packed, to_ndhwc
 from .nms import aligned_3d_nms
 from .registry import HEADS, build_loss
+from ._lib import raw_stream
 
 
 class Scale(nn.Module):
@@ -182,7 +183,7 @@ class ScanNetImVoxelHeadV2(nn.Module):
         meta = img_metas[0]
         pk = packed([self.centerness_conv, self.reg_conv, self.cls_conv])
         dev = x[0].device
-        st = c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        st = c_void_p(raw_stream(dev))
         gx0, gy0, gz0 = valid.shape[-3:]
         v0 = valid.reshape(gx0, gy0, gz0).float().contiguous()
         bests, labels, boxes = [], [], []

@@ -17,6 +17,7 @@ import torch
 from . import _lib, trace
 from .hostmath import matmul_fma_chain
 from ._lib import NDET_LAYOUT_CN, NDET_LAYOUT_NC, check, float3
+from ._lib import raw_stream
 
 Tensor = torch.Tensor
 
@@ -26,7 +27,7 @@ def _ptr(t: Optional[Tensor]):
 
 
 def _stream(t: Tensor):
-    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return c_void_p(raw_stream(t.device))
 
 
 def _need_gpu(*ts: Tensor):
