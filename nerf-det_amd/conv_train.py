@@ -460,7 +460,7 @@ def conv_forward(conv: nn.Module, x: Tensor) -> Tensor:
     if torch.is_grad_enabled() and eligible_transposed(conv, x):
         outs = []
         for b in range(x.shape[0]):
-            xb = _scene(x, b).permute(1, 2, 3, 0)
+            xb = C.carry_amax(x, _scene(x, b).permute(1, 2, 3, 0))      # (one scene of the batch: max |x[b]| <= max |x|, an upper bound is all the scale needs)
             outs.append(ConvT2.apply(xb if xb.is_contiguous() else xb.contiguous(), conv.weight).permute(3, 0, 1, 2))
         y = outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
         return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1, 1)
@@ -470,7 +470,7 @@ def conv_forward(conv: nn.Module, x: Tensor) -> Tensor:
     outs = []
     if three_d:
         for b in range(x.shape[0]):                                           # one scene at a time: the kernel's depth axis is X
-            xb = _scene(x, b).permute(1, 2, 3, 0)
+            xb = C.carry_amax(x, _scene(x, b).permute(1, 2, 3, 0))      # (one scene of the batch: max |x[b]| <= max |x|, an upper bound is all the scale needs)
             y = ConvS1.apply(xb if xb.is_contiguous() else xb.contiguous(), conv.weight, conv.stride[0])
             outs.append(y.permute(3, 0, 1, 2))
         y = outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
@@ -491,7 +491,7 @@ def conv_forward_shared(convs: Sequence[nn.Module], x: Tensor):
     w = torch.cat([c.weight for c in convs], dim=0)
     outs = []
     for b in range(x.shape[0]):
-        xb = _scene(x, b).permute(1, 2, 3, 0)
+        xb = C.carry_amax(x, _scene(x, b).permute(1, 2, 3, 0))      # (one scene of the batch: max |x[b]| <= max |x|, an upper bound is all the scale needs)
         outs.append(ConvS1.apply(xb if xb.is_contiguous() else xb.contiguous(), w).permute(3, 0, 1, 2))
     y = outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
     res, o = [], 0
