@@ -337,7 +337,8 @@ int ndet_amax_slot_floats(void);
  * (default 32 MiB); "order2": 1 / 0 = deal the column tiles of a row tile to one XCD or keep grid order (neither changes a result bit);
  * "deterministic_scatter": 1 = the backward kernels' gradient scatter on 64-bit fixed-point integer atomics (the caller then passes zeroed int64
  * buffers in place of the float ones: order-independent sums, for reproducibility tests; nerfdet_amd/autograd.py::set_deterministic);
- * "wgrad_wide": 0 = ndet_wgrad_split_f16x2 keeps its 128 x 128 tile where it would take 128 x 256 (same sums in another association).
+ * "wgrad_wide": 0 = ndet_wgrad_split_f16x2 keeps its 128 x 128 tile where it would take 128 x 256 (same sums in another association);
+ * "wgrad_xcd": 0 = the weight-gradient kernel's workgroups in grid order instead of one K split per XCD at a time (no result bit changes).
  * HOST string.  No reference counterpart (the reference's harness, tools/benchmark.py:63-89, times the model only). */
 int ndet_measurement_knob(const char* name_host, int64_t value);
 

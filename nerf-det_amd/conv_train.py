@@ -238,10 +238,14 @@ def weight_grad(x: Tensor, g: Tensor, kernel: Sequence[int], stride: int = 1, pa
         from . import _lib
         planes = pk["w_f16"][0] if f16 else C.split_planes(pk)
         bm = 128 if cin % 128 == 0 else 64
-        bn = 256 if (f16 and bm == 128 and cout % 256 == 0) else (128 if cout > 64 else 64)      # (the library's own choice: ndet_wgrad_split*)
+        bn = 256 if (f16 and bm == 128 and cout % 256 == 0 and taps * (cin // 128) >= 32) else (128 if cout > 64 else 64)      # (the library's own choice: ndet_wgrad_split*)
         tiles = (taps * cin // bm) * ((cout + bn - 1) // bn)
         ksteps = lrow // 32
-        splits = max(1, min(32, ksteps // 8, -(-768 // tiles)))
+        # ~1 000 workgroups of the 128 x 128 tile (768 left the FPN's 36-tile layer at 24 splits: 1 505 us against 1 260 at 32), ~800 of the 128 x 256
+        # tile (the neck's 54-tile layers: 16 splits 439 us, 24 splits 477 us) -- tools/diag/wgrad_ab.py
+        splits = max(1, min(32, ksteps // 8, -(-(768 if bn == 256 else 1024) // tiles)))
+        if splits >= 6:
+            splits = min(32, (splits + 7) // 8 * 8)           # a multiple of 8: one K split per XCD at a time (k_wgrad_split: the tiles of a split share its slice of x and dy in that L2)
         m = taps * cin
         ws = torch.empty((splits * m * cout,), dtype=torch.float32, device=x.device) if splits > 1 else None
         keep = f16 and splits > 1 and taps <= 27       # the partials go straight to ndet_wgrad_to_torch: no reduction pass, no (m, cout) intermediate

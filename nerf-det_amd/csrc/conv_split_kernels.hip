@@ -538,6 +538,7 @@ struct WgradParams {
     int ksteps;            // K steps of 32 voxels (dy rows are zero-filled past L)
     const float* x_amax = nullptr;    // fp16-pair arithmetic (SCH 1): the amax slots of x (split here, scaled by conv_xscale of its slot) and of dy (whose
     const float* dy_amax = nullptr;   // planes ndet_wgrad_dy_planes_f16x2 scaled the same way); the epilogue multiplies by the inverse of both
+    int xcd_order = 0;                // 1 (splits % 8 == 0): the tiles of one K split run on one XCD (see the kernel)
 };
 
 template <int BM, int BN, int SCH>
@@ -557,7 +558,20 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(const WgradParams g, con
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // Which workgroups meet in one XCD's L2 (workgroup b of the dispatch order runs on XCD b % 8).  In grid order the tiles of one K split are dealt
+    // round-robin over all eight XCDs, so every L2 sees every split's slice of x and dy and none can keep it (27-tap 256 -> 256 layer: 2.8 GB pulled per
+    // launch, mostly across the fabric).  With the splits a multiple of 8, XCD c takes the splits c, c + 8, ... one after the other, all tiles of a
+    // split side by side in time: they walk the same voxels, and the slice they share stays in that L2.  Same sums, same partial layout.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.xcd_order) {
+        const int gx = gridDim.x, T = gx * (int)gridDim.y;
+        const int b = bx + gx * (by + (int)gridDim.y * bz);
+        const int xcd = b & 7, slot = b >> 3;
+        bz = xcd + 8 * (slot / T);
+        const int tile = slot % T;
+        bx = tile % gx; by = tile / gx;
+    }
+    const int m0 = bx * BM, n0 = by * BN;
     const int tap = m0 / g.Cin, ci0 = m0 - tap * g.Cin;    // Cin % BM == 0: a tile never straddles two taps
     const int ta = tap / (g.kh * g.kw), tb = (tap / g.kw) % g.kh, tc = tap % g.kw;
     const int cq = tid % CQ, vg = tid / CQ;
@@ -567,8 +581,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(const WgradParams g, con
     const float osc = SCH == 1 ? conv_xinv_of(conv_amax_read(g.x_amax)) * conv_xinv_of(conv_amax_read(g.dy_amax)) : 1.0f;
     int it_begin = 0, it_end = g.ksteps;
     if (p.splits > 1) {
-        it_begin = (int)((int64_t)g.ksteps * blockIdx.z / p.splits);
-        it_end = (int)((int64_t)g.ksteps * (blockIdx.z + 1) / p.splits);
+        it_begin = (int)((int64_t)g.ksteps * bz / p.splits);
+        it_end = (int)((int64_t)g.ksteps * (bz + 1) / p.splits);
     }
     // output voxel of each of this thread's VT slots (consecutive voxels vg*VT .. +VT-1 of the step), advanced by 32 per step
     int od[VT], oh[VT], ow[VT];
@@ -700,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(const WgradParams g, con
         }
         __syncthreads();
         float mx_unused = 0.0f;
-        conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, 0, blockIdx.z, mx_unused, osc);
+        conv_store_rows<BN, NTHR>(p, Cs, CLDC, m0 + h * WM, WM, n0, tid, 0, bz, mx_unused, osc);
         __syncthreads();
     }
 }
@@ -1711,6 +1725,7 @@ static int64_t g_nt_bytes = (int64_t)32 << 20;
 static bool g_order2 = true;
 static int64_t conv_nt_bytes() { return g_nt_bytes; }
 static int g_wgrad_wide = 1;     // measurement knob "wgrad_wide": 0 = the 128 x 128 weight-gradient tile for every layer
+static int g_wgrad_xcd = 1;      // measurement knob "wgrad_xcd": 0 = grid order for the weight-gradient kernel's workgroups
 
 extern "C" int ndet_measurement_knob(const char* name, int64_t value) {
     const char* fn = "ndet_measurement_knob";
@@ -1719,7 +1734,8 @@ extern "C" int ndet_measurement_knob(const char* name, int64_t value) {
     if (!strcmp(name, "order2")) { NDET_REQUIRE(value == 0 || value == 1, NDET_E_INVALID, "%s: order2 is 0 or 1", fn); g_order2 = value != 0; return NDET_OK; }
     if (!strcmp(name, "deterministic_scatter")) { NDET_REQUIRE(value == 0 || value == 1, NDET_E_INVALID, "%s: deterministic_scatter is 0 or 1", fn); g_ndet_deterministic_scatter = (int)value; return NDET_OK; }
     if (!strcmp(name, "wgrad_wide")) { NDET_REQUIRE(value == 0 || value == 1, NDET_E_INVALID, "%s: wgrad_wide is 0 or 1", fn); g_wgrad_wide = (int)value; return NDET_OK; }
-    ndet_set_error("%s: unknown knob '%s' (nt_bytes, order2, deterministic_scatter, wgrad_wide)", fn, name);
+    if (!strcmp(name, "wgrad_xcd")) { NDET_REQUIRE(value == 0 || value == 1, NDET_E_INVALID, "%s: wgrad_xcd is 0 or 1", fn); g_wgrad_xcd = (int)value; return NDET_OK; }
+    ndet_set_error("%s: unknown knob '%s' (nt_bytes, order2, deterministic_scatter, wgrad_wide, wgrad_xcd)", fn, name);
     return NDET_E_INVALID;
 }
 extern "C" int ndet_amax_slot_floats(void) { return NDET_AMAX_SUB * NDET_AMAX_STRIDE; }
@@ -2288,6 +2304,7 @@ static int wgrad_split_entry(const char* fn, const float* x_ndhwc, int D, int H,
     p.splits = splits < 1 ? 1 : splits;
     NDET_REQUIRE(p.splits <= g.ksteps, NDET_E_INVALID, "%s: splits=%d exceeds the %d K steps", fn, p.splits, g.ksteps);
     NDET_REQUIRE(p.splits == 1 || workspace != nullptr, NDET_E_INVALID, "%s: split-K needs a workspace", fn);
+    g.xcd_order = (g_wgrad_xcd && p.splits >= 8 && p.splits % 8 == 0) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool wide = Cout > 64, big = Cin % 128 == 0;
     const int sch = max_order == 0 ? 2 : (max_order == 1 ? 1 : 0);
@@ -2296,7 +2313,9 @@ static int wgrad_split_entry(const char* fn, const float* x_ndhwc, int D, int H,
     // 256 output channels per workgroup where the layer has them (fp16 pairs; the 3-plane arithmetic's LDS tiles would not leave room for two
     // workgroups per CU): the kernel is bound by what it pulls through L2 -- every (tap, channel tile) re-reads dy, every column tile re-reads x;
     // measured on the neck's 27-tap 256 -> 256 layer at 128 x 128: 2.8 GB per launch, 6.2 TB/s -- and the wider tile halves the x side
-    if (big && sch == 1 && Cout % 256 == 0 && g_wgrad_wide) {
+    // (layers with fewer than 32 row tiles keep 128 x 128: the FPN's 9-tap 256 -> 256 layer over 192 000 pixels has 18, and with the K splits capped
+    // at 32 the wide tile leaves it 576 workgroups -- measured 1 413 us against 1 247 us)
+    if (big && sch == 1 && Cout % 256 == 0 && taps * (Cin / 128) >= 32 && g_wgrad_wide) {
         static bool attr_set[64] = {};
         int dev = 0;
         (void)hipGetDevice(&dev);
