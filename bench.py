@@ -385,6 +385,11 @@ def main():
 
     for _ in range(args.warmup):
         res = step()
+    # the model's ~10^5 long-lived Python objects out of the cyclic collector's reach (what a serving process does after start-up): a full collection
+    # in the middle of the timed steps walks all of them
+    import gc
+    gc.collect()
+    gc.freeze()
     trace.recorder = rec
     barrier()
     torch.cuda.synchronize()

@@ -123,6 +123,9 @@ def main():
     rec = trace.Recorder(sample=lambda name: (not name.startswith(("k_conv", "k_bottleneck", "k_point_mlp", "f32:", "bf16x3:", "bf16:", "f16x2:"))) or state["step"] % 4 == 0)
     for _ in range(args.warmup):
         out = train_one_step(model, data, opt)
+    import gc
+    gc.collect()
+    gc.freeze()          # the model's long-lived Python objects out of the cyclic collector's reach for the timed steps (bench.py does the same)
     trace.recorder = rec
     if grouped:
         torch.distributed.barrier()
