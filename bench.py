@@ -332,6 +332,7 @@ def main():
     ap.add_argument("--conv-arithmetic", default=None, choices=["f32", "bf16x3", "bf16", "f16x2"],
                     help="convolution kernel family (default: the package default, nerfdet_amd.conv3d.ARITHMETIC)")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-gc-freeze", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -389,7 +390,8 @@ def main():
     # in the middle of the timed steps walks all of them
     import gc
     gc.collect()
-    gc.freeze()
+    if not args.no_gc_freeze:
+        gc.freeze()
     trace.recorder = rec
     barrier()
     torch.cuda.synchronize()

@@ -288,28 +288,31 @@ class ScanNetImVoxelHeadV2(nn.Module):
                                                    c_void_p(keep.data_ptr()), c_void_p(n_keep.data_ptr()), c_void_p(ws.data_ptr()),
                                                    c_void_p(packed_out.data_ptr()), k_cap, c_void_p(0 if gw is None else gw.data_ptr()), st),
                       "nms_pack_detections")
-                # the picks land in pinned memory in the immediate form too (it collects its own handle below): a pageable ``.cpu()`` stages
-                # the copy through a bounce buffer and blocks the host for both legs
-                # every handle owns its pinned landing buffer + event until it is collected: a scene queued on the same stream before
-                # the previous handle's finish() ran must not overwrite that scene's picks.  Collected pairs return to a free list.
-                free = bufs.setdefault(("pinned-free", k_cap), [])
-                pin = free.pop() if free else [torch.empty((4 + k_cap * 9,), dtype=torch.float32).pin_memory(), torch.cuda.Event()]
-                pin[0].copy_(packed_out, non_blocking=True)
-                pin[1].record(stream)
-                state = {"res": None}
+                if defer:
+                    # every handle owns its pinned landing buffer + event until it is collected: a scene queued on the same stream before
+                    # the previous handle's finish() ran must not overwrite that scene's picks.  Collected pairs return to a free list.
+                    free = bufs.setdefault(("pinned-free", k_cap), [])
+                    pin = free.pop() if free else [torch.empty((4 + k_cap * 9,), dtype=torch.float32).pin_memory(), torch.cuda.Event()]
+                    pin[0].copy_(packed_out, non_blocking=True)
+                    pin[1].record(stream)
+                    state = {"res": None}
 
-                def finish():
-                    if state["res"] is None:                                  # a handle may be collected more than once
-                        pin[1].synchronize()                                  # the scene's one host sync, whenever the caller gets to it
-                        got = fast(pin[0].clone())
-                        free.append(pin)
-                        if got is None:
-                            with torch.cuda.stream(stream):
-                                got = Detections(general())
-                                got.range_guard = guard_tripped(dev)
-                        state["res"] = got
-                    return state["res"]
-                return finish if defer else finish()                      # (finish() falls back to the host-driven tail by itself)
+                    def finish():
+                        if state["res"] is None:                                  # a handle may be collected more than once
+                            pin[1].synchronize()                                  # the scene's one host sync, whenever the caller gets to it
+                            got = fast(pin[0].clone())
+                            free.append(pin)
+                            if got is None:
+                                with torch.cuda.stream(stream):
+                                    got = Detections(general())
+                                    got.range_guard = guard_tripped(dev)
+                            state["res"] = got
+                        return state["res"]
+                    return finish
+                # (a pinned landing buffer + event wait, as the deferred form uses, measured 0.4 % SLOWER here in same-box alternating runs: kept pageable)
+                got = fast(packed_out.cpu())                                  # the one host sync of the scene
+                if got is not None:
+                    return got
             res = Detections(general())
             res.range_guard = guard_tripped(dev)           # (the host-driven tail has synchronised already)
             return (lambda: res) if defer else res
