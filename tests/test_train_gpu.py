@@ -127,8 +127,8 @@ def test_bf16_gradients_point_along_the_fp32_class_gradients_at_cfg3_shapes(devi
     """BASELINE configs[2] trains in bf16: one step at its per-rank shapes (40 source + 10 target views 240x320, 40x40x16 voxels, 2 048 rays x 64
     samples) in three arithmetics, same rays and sampling noise.
 
-    * exact fp32-MFMA kernels vs the fp32-class bf16x3 kernels: the two independent kernel families must agree per parameter group to
-      cosine >= 0.9999 and 1 % in norm -- this is the check that no backward path is wrong (it would have caught the library's
+    * exact fp32-MFMA kernels and the default fp16-pair training arithmetic vs the fp32-class bf16x3 kernels: the independent kernel families
+      must agree per parameter group to cosine >= 0.9999 and 1 % in norm -- this is the check that no backward path is wrong (it would have caught the library's
       channels-last-3d backward, DESIGN.md 9.2);
     * bf16 vs fp32-class: every single layer is within 2.4e-3 of fp64 in output, data and weight gradient (operand rounding, measured
       layer by layer), but a bf16 forward flips the ReLU mask of the ~0.5 % of units whose pre-activation lies within its error, and
@@ -146,7 +146,7 @@ def test_bf16_gradients_point_along_the_fp32_class_gradients_at_cfg3_shapes(devi
     det.to(device).train()
     scene = batch_to(train_scene(40, (240, 320), t_views=10, n_boxes=8, seed=4), device)
     grads = {}
-    for mode in ("bf16x3", "f32", "bf16"):
+    for mode in ("bf16x3", "f32", "bf16", "f16x2"):
         prev = conv3d.set_arithmetic(mode)
         try:
             rays.rng = np.random.RandomState(234)
@@ -159,16 +159,19 @@ def test_bf16_gradients_point_along_the_fp32_class_gradients_at_cfg3_shapes(devi
         finally:
             conv3d.set_arithmetic(prev)
     report = {}
-    for mode in ("f32", "bf16"):
+    for mode in ("f32", "bf16", "f16x2"):
         for g in GROUPS:
             a, b = grads["bf16x3"][g].double(), grads[mode][g].double()
             assert a.numel() > 0 and float(a.norm()) > 0, g
             report[(mode, g)] = (float(torch.dot(a, b) / (a.norm() * b.norm())), float(b.norm() / a.norm()))
-    for mode in ("f32", "bf16"):
+    for mode in ("f32", "bf16", "f16x2"):
         print(f"{mode} vs fp32-class gradients (cosine, norm ratio):", {g: (round(report[(mode, g)][0], 5), round(report[(mode, g)][1], 4)) for g in GROUPS})
     for g in GROUPS:
         c, r = report[("f32", g)]
         assert c >= 0.9999 and abs(r - 1) <= 0.01, f"{g}: the two fp32-class kernel families disagree: cosine {c:.6f}, norm ratio {r:.4f}"
+        # the DEFAULT training arithmetic (fp16 pairs with device-side scales, conv3d.TRAIN_F16X2) is held to the same bar as the exact kernels
+        c, r = report[("f16x2", g)]
+        assert c >= 0.9999 and abs(r - 1) <= 0.01, f"{g}: the fp16-pair training arithmetic leaves the fp32-class gradients: cosine {c:.6f}, norm ratio {r:.4f}"
         c, r = report[("bf16", g)]
         assert c >= 0.95, f"{g}: bf16 cosine {c:.5f}"
         assert abs(r - 1) <= 0.12, f"{g}: bf16 norm ratio {r:.4f}"
