@@ -37,7 +37,9 @@ def _raw_pack(w_taps_co_ci: Tensor, kernel: Sequence[int], stride: int = 1, pads
 
 
 _STEP_SLOTS = {}      # (weight address, version) -> amax slot, filled by prepare_step for ONE step (cleared by the next call)
-_STEP_PARAMS = {}     # id(module) -> its convolution modules
+import weakref
+
+_STEP_PARAMS = weakref.WeakKeyDictionary()     # model -> its convolution modules (the entry goes with the model: no model is kept alive by it)
 
 
 def prepare_step(module: nn.Module) -> int:
@@ -47,9 +49,11 @@ def prepare_step(module: nn.Module) -> int:
     _STEP_SLOTS.clear()
     if C.train_arithmetic() != "f16x2":
         return 0
-    mods = _STEP_PARAMS.get(id(module))
+    mods = _STEP_PARAMS.get(module)
     if mods is None:      # the convolution MODULES are cached (a stable list); their weights are read off them every step (.to() / load_state_dict may replace them)
-        mods = _STEP_PARAMS[id(module)] = [m for m in module.modules() if isinstance(m, (nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d))]
+        mods = [m for m in module.modules() if isinstance(m, (nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d))]
+        if not any(m is module for m in mods):         # (a value that holds its own key would keep the entry alive for ever)
+            _STEP_PARAMS[module] = mods
     ws = [m.weight for m in mods if m.weight.requires_grad and m.weight.is_cuda and m.weight.dtype == torch.float32]
     if not ws:
         return 0
