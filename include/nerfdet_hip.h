@@ -136,6 +136,14 @@ int ndet_head_decode(const float* raw, int n_cls, const uint8_t* valid, const fl
                      const float* voxel_size_host, const float* origin_host, float* best, int64_t* label, float* boxes,
                      void* stream);
 
+/* ndet_level_valid + ndet_head_decode for up to four head levels in ONE launch (imvoxel_head_v2.py:262-271,442-449,547-555; the tail of the
+ * one-scene loop is a chain of tiny dependent kernels).  HOST arrays of per-level DEVICE pointers (raw, scale, best, label, boxes), HOST dims
+ * (3 ints per level), integer down-scale factors against the (X, Y, Z) float validity volume `valid` (1 or even, dims * factor == X, Y, Z), HOST
+ * voxel sizes (3 floats per level, already times 2^level) and origin.  Same arithmetic, level by level, as the two separate calls. */
+int ndet_head_decode_levels(int n_levels, const float* const* raw_host, const float* const* scale_host, const int* dims_host,
+                            const int* factor_host, const float* voxel_size_host, const float* origin_host, int n_cls, const float* valid, int X,
+                            int Y, int Z, float* const* best_host, int64_t* const* label_host, float* const* boxes_host, void* stream);
+
 /* valid mask of an FPN level: F.interpolate(valid, size, mode='trilinear').round().bool() of
  * mmdet3d/models/dense_heads/imvoxel_head_v2.py:442-449 for the integer down-scale `factor` (1 or even) of the level:
  * valid (X,Y,Z) float view counts -> out (X/f,Y/f,Z/f) uint8. */

@@ -38,6 +38,7 @@ SIGNATURES = {
     "ndet_nms_workspace_bytes": ([c_int], c_int64),
     "ndet_aligned_3d_nms": ([_P, _P, _P, c_int, c_float, _P, _P, _P, _P], c_int),
     "ndet_head_decode": ([_P, c_int, _P, _P, c_int, c_int, c_int, _F3, _F3, _P, _P, _P, _P], c_int),
+    "ndet_head_decode_levels": ([c_int, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P], c_int),
     "ndet_sample_along_rays": ([_P, _P, c_int, c_int, c_float, c_float, _P, _P, _P, _P], c_int),
     "ndet_ray_view_stats": ([_P, c_int, _P, c_int, c_float, c_float, _P, c_int, c_int, c_int64, c_int64, c_int64,
                              _P, c_int, c_int, c_int, c_int64, c_int64, _P, _P, _P, _P], c_int),

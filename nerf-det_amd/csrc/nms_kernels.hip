@@ -343,6 +343,105 @@ extern "C" int ndet_head_decode(const float* raw, int n_cls, const uint8_t* vali
     return NDET_OK;
 }
 
+// Every level's validity mask and decode in ONE launch (the one-scene loop's tail is a chain of tiny dependent kernels: six launches of ~5 us with
+// their gaps for what is 29 200 independent voxels at the configs' sizes).  Same arithmetic as k_level_valid + k_head_decode, level by level.
+struct DecodeLevels {
+    const float* raw[4];       // (X_l, Y_l, Z_l, 7 + n_cls) head outputs
+    const float* scale[4];     // the level's learnable Scale (device scalar)
+    float* best[4];
+    int64_t* label[4];
+    float* boxes[4];
+    int nx[4], ny[4], nz[4], f[4];     // level grid, integer down-scale against the full-resolution validity volume
+    float vx[4], vy[4], vz[4], ox[4], oy[4], oz[4];
+    int start[5];              // first global thread of each level (prefix sums of the voxel counts)
+    int n_levels, n_cls, X, Y, Z;
+    const float* valid;        // (X, Y, Z) floats
+};
+
+__global__ __launch_bounds__(256) void k_head_decode_levels(const DecodeLevels L) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L.start[L.n_levels]) return;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < L.n_levels && t >= L.start[k]) l = k;
+    const int n = t - L.start[l];
+    const int nx = L.nx[l], ny = L.ny[l], nz = L.nz[l], f = L.f[l];
+    const int iz = n % nz, iy = (n / nz) % ny, ix = n / (nz * ny);
+    // ---- k_level_valid ----
+    float vsum;
+    if (f == 1) vsum = L.valid[n];
+    else {
+        const int x0 = f * ix + f / 2 - 1, y0 = f * iy + f / 2 - 1, z0 = f * iz + f / 2 - 1;
+        vsum = 0.0f;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dz = 0; dz < 2; ++dz) vsum += 0.125f * L.valid[((int64_t)(x0 + dx) * L.Y + (y0 + dy)) * L.Z + (z0 + dz)];
+    }
+    const float v = rintf(vsum) != 0.0f ? 1.0f : 0.0f;
+    // ---- k_head_decode ----
+    const int stride = 7 + L.n_cls;
+    const float* r = L.raw[l] + (int64_t)n * stride;
+    const float ctr = 1.0f / (1.0f + expf(-r[0]));
+    float bs = -1.0f;
+    int bl = 0;
+    for (int k = 0; k < L.n_cls; ++k) {
+        const float sc = ((1.0f / (1.0f + expf(-r[7 + k]))) * ctr) * v;
+        if (sc > bs) { bs = sc; bl = k; }
+    }
+    L.best[l][n] = bs;
+    L.label[l][n] = bl;
+    const float px = (float)ix * L.vx[l] + L.ox[l], py = (float)iy * L.vy[l] + L.oy[l], pz = (float)iz * L.vz[l] + L.oz[l];
+    const float s = L.scale[l][0];
+    float d[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d[k] = expf(r[1 + k] * s);
+    float* b = L.boxes[l] + (int64_t)n * 6;
+    b[0] = px - d[0]; b[1] = py - d[2]; b[2] = pz - d[4];
+    b[3] = px + d[1]; b[4] = py + d[3]; b[5] = pz + d[5];
+}
+
+extern "C" int ndet_head_decode_levels(int n_levels, const float* const* raw_host, const float* const* scale_host, const int* dims_host,
+                                       const int* factor_host, const float* voxel_size_host, const float* origin_host, int n_cls, const float* valid,
+                                       int X, int Y, int Z, float* const* best_host, int64_t* const* label_host, float* const* boxes_host, void* stream) {
+    const char* fn = "ndet_head_decode_levels";
+    NDET_REQUIRE(raw_host && scale_host && dims_host && factor_host && voxel_size_host && origin_host && valid && best_host && label_host && boxes_host,
+                 NDET_E_INVALID, "%s: null pointer", fn);
+    NDET_REQUIRE(n_levels >= 1 && n_levels <= 4 && n_cls > 0 && X > 0 && Y > 0 && Z > 0, NDET_E_INVALID, "%s: 1..4 levels, positive sizes", fn);
+    DecodeLevels L;
+    L.n_levels = n_levels; L.n_cls = n_cls; L.X = X; L.Y = Y; L.Z = Z; L.valid = valid;
+    int64_t total = 0;
+    for (int l = 0; l < 4; ++l) {
+        if (l >= n_levels) {
+            L.raw[l] = nullptr; L.scale[l] = nullptr; L.best[l] = nullptr; L.label[l] = nullptr; L.boxes[l] = nullptr;
+            L.nx[l] = L.ny[l] = L.nz[l] = L.f[l] = 1; L.vx[l] = L.vy[l] = L.vz[l] = L.ox[l] = L.oy[l] = L.oz[l] = 0.0f;
+            continue;
+        }
+        const int nx = dims_host[3 * l], ny = dims_host[3 * l + 1], nz = dims_host[3 * l + 2], f = factor_host[l];
+        NDET_REQUIRE(raw_host[l] && scale_host[l] && best_host[l] && label_host[l] && boxes_host[l], NDET_E_INVALID, "%s: null pointer at level %d", fn, l);
+        NDET_REQUIRE(nx > 0 && ny > 0 && nz > 0 && f >= 1 && (f == 1 || f % 2 == 0) && nx * f == X && ny * f == Y && nz * f == Z, NDET_E_UNSUPPORTED,
+                     "%s: level %d (%d x %d x %d, factor %d) is not an integer (1 or even) down-scale of the %d x %d x %d validity volume", fn, l, nx, ny, nz, f, X, Y, Z);
+        L.raw[l] = raw_host[l]; L.scale[l] = scale_host[l]; L.best[l] = best_host[l]; L.label[l] = label_host[l]; L.boxes[l] = boxes_host[l];
+        L.nx[l] = nx; L.ny[l] = ny; L.nz[l] = nz; L.f[l] = f;
+        // the level's voxel pitch and the grid's corner, evaluated as ndet_head_decode does (volatile: no contraction of the host arithmetic)
+        const float sx = voxel_size_host[3 * l], sy = voxel_size_host[3 * l + 1], sz = voxel_size_host[3 * l + 2];
+        volatile float hx = (float)nx / 2.0f, hy = (float)ny / 2.0f, hz = (float)nz / 2.0f;
+        volatile float mx = hx * sx, my = hy * sy, mz = hz * sz;
+        L.vx[l] = sx; L.vy[l] = sy; L.vz[l] = sz;
+        L.ox[l] = origin_host[0] - mx; L.oy[l] = origin_host[1] - my; L.oz[l] = origin_host[2] - mz;
+        L.start[l] = (int)total;
+        total += (int64_t)nx * ny * nz;
+        NDET_REQUIRE(total < ((int64_t)1 << 31), NDET_E_UNSUPPORTED, "%s: too many voxels", fn);
+    }
+    for (int l = n_levels; l <= 4; ++l) L.start[l] = (int)total;
+    hipLaunchKernelGGL(k_head_decode_levels, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, L);
+    NDET_CHECK_LAUNCH(fn);
+    return NDET_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Head post-processing between the decode and the NMS in two launches instead of ~60 library kernels.
 //

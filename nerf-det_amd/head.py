@@ -187,26 +187,43 @@ class ScanNetImVoxelHeadV2(nn.Module):
         gx0, gy0, gz0 = valid.shape[-3:]
         v0 = valid.reshape(gx0, gy0, gz0).float().contiguous()
         bests, labels, boxes = [], [], []
-        for i, (f, sc) in enumerate(zip(x, self.scales)):
-            raw = conv3d_ndhwc(to_ndhwc(carry_amax(f, f[0]) if f.dtype == torch.float32 else f[0].float()), pk, amax=False)  # (X,Y,Z,25)
-            gx, gy, gz = raw.shape[:3]
-            n = gx * gy * gz
-            fac = gx0 // gx
-            if fac >= 1 and (fac == 1 or fac % 2 == 0) and (gx * fac, gy * fac, gz * fac) == (gx0, gy0, gz0):
-                v = torch.empty((n,), dtype=torch.uint8, device=dev)
-                check(lib.ndet_level_valid(c_void_p(v0.data_ptr()), gx0, gy0, gz0, fac, c_void_p(v.data_ptr()), st), "level_valid")
-            else:
-                v = nn.functional.interpolate(valid, size=(gx, gy, gz), mode="trilinear").round().bool().reshape(-1).contiguous()
-            best = torch.empty((n,), dtype=torch.float32, device=dev)
-            lab = torch.empty((n,), dtype=torch.int64, device=dev)
-            box = torch.empty((n, 6), dtype=torch.float32, device=dev)
-            vs = (torch.tensor(self.voxel_size) * (2 ** i)).tolist()
-            check(lib.ndet_head_decode(c_void_p(raw.data_ptr()), self.n_classes, c_void_p(v.data_ptr()), c_void_p(sc.scale.data_ptr()),
-                                       gx, gy, gz, float3(np.float32(vs)), float3(np.float32(np.asarray(meta["lidar2img"]["origin"]))),
-                                       c_void_p(best.data_ptr()), c_void_p(lab.data_ptr()), c_void_p(box.data_ptr()), st), "head_decode")
-            bests.append(best)
-            labels.append(lab)
-            boxes.append(box)
+        raws = [conv3d_ndhwc(to_ndhwc(carry_amax(f, f[0]) if f.dtype == torch.float32 else f[0].float()), pk, amax=False) for f in x]  # (X,Y,Z,25) each
+        grids = [tuple(r.shape[:3]) for r in raws]
+        facs = [gx0 // g[0] for g in grids]
+        org = np.float32(np.asarray(meta["lidar2img"]["origin"]))
+        if len(raws) <= 4 and all(fc >= 1 and (fc == 1 or fc % 2 == 0) and (g[0] * fc, g[1] * fc, g[2] * fc) == (gx0, gy0, gz0) for fc, g in zip(facs, grids)):
+            # every level's validity mask + decode in one launch (csrc/nms_kernels.hip::k_head_decode_levels)
+            nlv = len(raws)
+            for g in grids:
+                n = g[0] * g[1] * g[2]
+                bests.append(torch.empty((n,), dtype=torch.float32, device=dev))
+                labels.append(torch.empty((n,), dtype=torch.int64, device=dev))
+                boxes.append(torch.empty((n, 6), dtype=torch.float32, device=dev))
+            vp = lambda ts: (ctypes.c_void_p * nlv)(*[t.data_ptr() for t in ts])
+            vsz = np.concatenate([np.float32((torch.tensor(self.voxel_size) * (2 ** i)).tolist()) for i in range(nlv)]).astype(np.float32)
+            check(lib.ndet_head_decode_levels(nlv, vp(raws), vp([sc.scale for sc in self.scales][:nlv]), (ctypes.c_int * (3 * nlv))(*[v for g in grids for v in g]),
+                                              (ctypes.c_int * nlv)(*facs), vsz.ctypes.data_as(c_void_p), org.ctypes.data_as(c_void_p), self.n_classes,
+                                              c_void_p(v0.data_ptr()), gx0, gy0, gz0, vp(bests), vp(labels), vp(boxes), st), "head_decode_levels")
+        else:
+            for i, (raw, sc) in enumerate(zip(raws, self.scales)):
+                gx, gy, gz = raw.shape[:3]
+                n = gx * gy * gz
+                fac = facs[i]
+                if fac >= 1 and (fac == 1 or fac % 2 == 0) and (gx * fac, gy * fac, gz * fac) == (gx0, gy0, gz0):
+                    v = torch.empty((n,), dtype=torch.uint8, device=dev)
+                    check(lib.ndet_level_valid(c_void_p(v0.data_ptr()), gx0, gy0, gz0, fac, c_void_p(v.data_ptr()), st), "level_valid")
+                else:
+                    v = nn.functional.interpolate(valid, size=(gx, gy, gz), mode="trilinear").round().bool().reshape(-1).contiguous()
+                best = torch.empty((n,), dtype=torch.float32, device=dev)
+                lab = torch.empty((n,), dtype=torch.int64, device=dev)
+                box = torch.empty((n, 6), dtype=torch.float32, device=dev)
+                vs = (torch.tensor(self.voxel_size) * (2 ** i)).tolist()
+                check(lib.ndet_head_decode(c_void_p(raw.data_ptr()), self.n_classes, c_void_p(v.data_ptr()), c_void_p(sc.scale.data_ptr()),
+                                           gx, gy, gz, float3(np.float32(vs)), float3(org),
+                                           c_void_p(best.data_ptr()), c_void_p(lab.data_ptr()), c_void_p(box.data_ptr()), st), "head_decode")
+                bests.append(best)
+                labels.append(lab)
+                boxes.append(box)
         nl = len(bests)
         if nl <= 4:
             sizes = [int(b.shape[0]) for b in bests]
