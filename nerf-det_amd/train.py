@@ -94,12 +94,15 @@ def train_one_step(model, data: Dict, optimizer, grad_clip: float = 35.0, lazy_l
     host floats -- the step then ends without a host synchronisation."""
     optimizer.zero_grad(set_to_none=True)
     module = model.module if isinstance(model, DistributedDataParallel) else model
-    if any(p.is_cuda for p in module.parameters()):
+    if next(module.parameters()).is_cuda:
         from . import conv_train
         conv_train.prepare_step(module)                         # fp16-pair training: every convolution weight's max |w| in two launches
     out = model.train_step(data, optimizer, defer_log=True)     # logged scalars stay on the device until the whole step is queued
     out["loss"].backward()
-    params = [p for p in module.parameters() if p.requires_grad and p.grad is not None]
+    # the optimizer's own parameter lists (build_optimizer: every trainable parameter of the model) instead of another walk over the module tree
+    # (named_members over ~200 modules: ~0.7 ms of host time per step)
+    params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None] if optimizer is not None else \
+        [p for p in module.parameters() if p.requires_grad and p.grad is not None]
     norm = torch.nn.utils.clip_grad_norm_(params, grad_clip) if grad_clip and params else None
     optimizer.step()
     names = list(out["log_vars"]) + (["grad_norm"] if norm is not None else [])
