@@ -151,4 +151,5 @@ def raw_stream(device) -> int:
     idx = device.index if isinstance(device, torch.device) else (torch.device(device).index if isinstance(device, str) else device)
     if idx is None:
         idx = torch.cuda.current_device()
-    return torch._C._cuda_getCurrentRawStream(idx)
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    return raw(idx) if raw is not None else torch.cuda.current_stream(idx).cuda_stream      # (private getter: the public path if a build lacks it)
