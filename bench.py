@@ -333,6 +333,7 @@ def main():
                     help="convolution kernel family (default: the package default, nerfdet_amd.conv3d.ARITHMETIC)")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-gc-freeze", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-chain-mapping", action="store_true", help=argparse.SUPPRESS)     # measurement: the feature mapping as a launch of its own
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -359,6 +360,8 @@ def main():
     det = build_model(w)
     batch_cpu = synth_batch(w, rank)
     det_gpu = det.to(device)
+    if args.no_chain_mapping and "chain_linear" in det_gpu.neck.__dict__:
+        det_gpu.neck.__dict__["chain_linear"] = None
     batch = to_device(batch_cpu, device)
     if args.conv_arithmetic:
         C3.set_arithmetic(args.conv_arithmetic)

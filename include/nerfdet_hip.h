@@ -375,6 +375,16 @@ int ndet_conv_ndhwc_guarded(const float* in, const uint16_t* w_planes, float* ou
                             const float* in_amax, float w_inv_scale, float* out_amax, void* workspace, float guard_l1, float guard_tol,
                             unsigned* guard, void* stream);
 
+/* ndet_conv_ndhwc_guarded (plain stride-1 same-padded convolution, no residual / ReLU / split-K) with a chained 32-channel projection of every output
+ * row in the same launch: map_out (M, 32) = out_row . map_w + map_b, map_w (Cout, 32) and map_b (32) with the convolution's own affine folded in by
+ * the caller (map_w[c][j] = scale_c Wm[j][c], map_b[j] = sum_c shift_c Wm[j][c] + bm[j]); fp32 FMAs.  The detector's feature mapping
+ * (mmdet3d/models/detectors/nerfdet.py:194-197: self.mapping on every FPN level-0 pixel) behind the FPN output convolution (nerfdet.py:140-142): the
+ * 276 MB feature map is not read back by a launch of its own.  Only the 256-column halo tiles own whole rows: tile 3256 / 3257 / 3258, Cout = 256. */
+int ndet_conv_ndhwc_mapped(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout, const int* kernel,
+                           const int* stride, const int* pad, const float* scale, const float* shift, int tile, int arith, const float* in_amax,
+                           float w_inv_scale, float* out_amax, float guard_l1, float guard_tol, unsigned* guard, const float* map_w,
+                           const float* map_b, float* map_out, void* stream);
+
 /* ndet_conv_chain_arith with the range guard (see ndet_conv_ndhwc_guarded): guard_l1 belongs to w_planes and max|in|, guard_l1_3 to w3_planes and
  * the chained product (reserved: its operand is scaled by each workgroup's own maximum, which needs no check).  The bottleneck tail of the backbone called at mmdet3d/models/detectors/nerfdet.py:140. */
 int ndet_conv_chain_guarded(const float* in, const uint16_t* w_planes, int D, int H, int W, int Cin, int Cmid, const int* kernel,

@@ -89,6 +89,7 @@ SIGNATURES = {
     "ndet_bn_train_backward": ([_P, _P, _P, c_int64, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P], c_int),
     "ndet_wgrad_to_torch": ([_P, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ndet_split_weights_train": ([_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P], c_int),
+    "ndet_conv_ndhwc_mapped": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, c_float, _P, c_float, c_float, _P, _P, _P, _P, _P], c_int),
     "ndet_conv_ndhwc_train": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P], c_int),
     "ndet_relu_affine_bwd": ([_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P], c_int),
     "ndet_relu_affine_bwd_amax": ([_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P], c_int),

@@ -213,6 +213,25 @@ class _Conv(nn.Module):
         return conv_forward(self.conv, x)
 
 
+def _chain_pack(pk: dict, lin: nn.Linear):
+    """(map_w (Cout, 32), map_b (32)) of conv3d.conv2d_nhwc's chained projection for ``lin`` behind the convolution packed as ``pk``: the
+    convolution's own per-channel affine (bias / folded BatchNorm) is folded in, out = (acc * scale + shift) . Wm^T + bm.  Cached on the Linear."""
+    store = lin.__dict__.setdefault("_ndet_chain", {})
+    stamp = (lin.weight.data_ptr(), lin.weight._version, lin.bias.data_ptr(), lin.bias._version, id(pk),
+             None if pk["scale"] is None else (pk["scale"].data_ptr(), pk["scale"]._version), None if pk["shift"] is None else (pk["shift"].data_ptr(), pk["shift"]._version))
+    hit = store.get("pack")
+    if hit is None or hit[0] != stamp:
+        with torch.no_grad():
+            wm, bm = lin.weight.detach().float(), lin.bias.detach().float()
+            scale = pk["scale"] if pk["scale"] is not None else torch.ones(pk["cout"], device=wm.device)
+            shift = pk["shift"] if pk["shift"] is not None else torch.zeros(pk["cout"], device=wm.device)
+            map_w = (wm * scale.view(1, -1)).t().contiguous()
+            map_b = (wm @ shift + bm).contiguous()
+        hit = (stamp, (map_w, map_b), pk)          # (pk kept alive: its id is part of the stamp)
+        store["pack"] = hit
+    return hit[1]
+
+
 @NECKS.register_module()
 class FPN(nn.Module):
     """1x1 laterals, top-down nearest upsample-add, 3x3 output convs; no extra levels when
@@ -226,6 +245,7 @@ class FPN(nn.Module):
         self.lateral_convs = nn.ModuleList(_Conv(c, out_channels, 1) for c in in_channels)
         self.fpn_convs = nn.ModuleList(_Conv(out_channels, out_channels, 3, 1) for _ in in_channels)
         self.active_outs = None  # None = all
+        self.__dict__["chain_linear"] = None   # set by the detector (not a submodule: the Linear stays the detector's): see forward_hip
 
     def init_weights(self):
         for m in self.modules():
@@ -254,4 +274,21 @@ class FPN(nn.Module):
             lat[i] = conv2d_nhwc(_nhwc(inputs[i]), packed([self.lateral_convs[i].conv]), residual=lat[i + 1] if i + 1 < n else None,
                                  residual_up2=i + 1 < n)
         act = range(n) if self.active_outs is None else self.active_outs
-        return tuple(conv2d_nhwc(lat[i], packed([self.fpn_convs[i].conv]), amax=False).permute(0, 3, 1, 2) if i in act else None for i in range(n))
+        outs = []
+        for i in range(n):
+            if i not in act:
+                outs.append(None)
+                continue
+            pk = packed([self.fpn_convs[i].conv])
+            lin = self.chain_linear if i == 0 else None
+            if lin is not None and lin.in_features == pk["cout"] == 256 and lin.out_features == 32 and lin.weight.is_cuda:
+                # the detector's 256 -> 32 feature mapping (nerfdet.py:194-197) rides in the level-0 output convolution's epilogue: the mapped map
+                # travels on the output tensor as ``_ndet_feature_2d`` (logical (N, 32, H, W), channels-last memory)
+                o, mapped = conv2d_nhwc(lat[i], pk, amax=False, chain=_chain_pack(pk, lin))
+                o = o.permute(0, 3, 1, 2)
+                if mapped is not None:
+                    o._ndet_feature_2d = mapped.view(o.shape[0], o.shape[2], o.shape[3], 32).permute(0, 3, 1, 2)
+                outs.append(o)
+            else:
+                outs.append(conv2d_nhwc(lat[i], pk, amax=False).permute(0, 3, 1, 2))
+        return tuple(outs)

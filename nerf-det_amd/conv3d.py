@@ -358,7 +358,7 @@ def layer_arithmetic(k_iters: int) -> str:
     return ARITHMETIC
 
 
-def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, residual_up2, relu, splits, tile, m, k_iters, flops, want_amax=True):
+def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, residual_up2, relu, splits, tile, m, k_iters, flops, want_amax=True, chain=None):
     halo_ok = (not transposed and all(s == 1 for s in stride) and all(k % 2 == 1 and q == k // 2 for k, q in zip(kernel, pad))
                and kernel[0] * kernel[1] * kernel[2] > 1)
     tile, splits = choose_tiling_split(m, pk["cout"], k_iters, tile, 1 if (transposed or residual_up2) else splits, transposed, halo_ok)
@@ -420,6 +420,19 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
     out_amax = AMAX.take(x.device) if want_amax else None
     gw = guard_word(x.device) if arith == "f16x2" else None
     gl1 = guard_l1(pk) if gw is not None else 0.0
+    if chain is not None:
+        # the chained 32-channel projection of the output rows in the same launch (csrc: conv_map_rows): the 256-column halo tiles only
+        mapped = None
+        if tile in (3256, 3257, 3258) and splits == 1 and residual is None and relu == 0 and not transposed and pk["cout"] == 256 and arith in ("f16x2", "bf16x3"):
+            mapped = torch.empty((m, 32), dtype=torch.float32, device=x.device)
+            _launch(flops, lambda: check(lib.ndet_conv_ndhwc_mapped(_ptr(x), _ptr(planes), _ptr(out), d, h, w, pk["cin"], pk["cout"], i3(kernel), i3(stride), i3(pad),
+                                                                    _ptr(pk["scale"]), _ptr(pk["shift"]), tile, 1 if arith == "f16x2" else 0, _ptr(in_amax), winv,
+                                                                    _ptr(out_amax), gl1, GUARD_TOL, _ptr(gw), _ptr(chain[0]), _ptr(chain[1]), _ptr(mapped), st),
+                                         "conv_ndhwc_mapped"), arith, tile, nbytes + 4 * mapped.numel())
+            if want_amax:
+                _tag_amax(out, out_amax)
+            return out, mapped
+        chain = None      # another tile / arithmetic took the layer: the caller projects in a launch of its own
     _launch(flops, lambda: check(lib.ndet_conv_ndhwc_guarded(_ptr(x), _ptr(planes), _ptr(out), d, h, w, pk["cin"], pk["cout"], i3(kernel), i3(stride), i3(pad),
                                                              int(transposed), _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), int(residual_up2), relu,
                                                              splits, tile, 1 if arith == "f16x2" else 0, _ptr(in_amax), winv, _ptr(out_amax), _ptr(ws),
@@ -428,6 +441,11 @@ def _conv_split(x, pk, out, dims, kernel, stride, pad, transposed, residual, res
     if want_amax:
         _tag_amax(out, out_amax)
     return out
+
+
+def projection_ok() -> bool:
+    """Does the current arithmetic have the chained-projection epilogue (conv2d_nhwc(..., chain=...))?"""
+    return ARITHMETIC == "f16x2"
 
 
 def _ptr(t):
@@ -571,9 +589,12 @@ def conv3d_ndhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = N
 
 
 def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = None, relu: int = 0, splits: int = 0, tile: int = 0,
-                residual_up2: bool = False, amax: bool = True):
+                residual_up2: bool = False, amax: bool = True, chain=None):
     """Batch of 2D maps, x (N,H,W,Cin) contiguous fp32 -> (N,OH,OW,Cout): Conv2d (+ eval BatchNorm2d / bias) + ReLU +
-    residual in one pass of the MFMA kernel (the batch is the kernel's depth axis with extent-1 taps)."""
+    residual in one pass of the MFMA kernel (the batch is the kernel's depth axis with extent-1 taps).
+
+    ``chain`` = (map_w (Cout, 32), map_b (32)) (fp16-pair mode, :func:`projection_ok`): returns ``(out, mapped)`` with ``mapped`` (N*OH*OW, 32) the
+    projection of every output row computed in the same launch -- or ``(out, None)`` when the layer's tile cannot take it."""
     if not x.is_cuda:
         raise RuntimeError("nerfdet_amd.conv3d: tensors must live on the GPU (no CPU fallback)")
     assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32 and pk["ndim"] == 2
@@ -588,9 +609,13 @@ def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = No
         if residual_up2:
             splits = 1
     m = n * oh * ow
+    pair = chain is not None                       # the caller unpacks (out, mapped) whatever path the layer takes
     if ARITHMETIC in SPLIT_FAMILY:
-        return _conv_split(x, pk, out, (n, h, w), (1, kh, kw), (1, sh, sw), (0, ph, pw), False, residual, residual_up2, relu, splits, tile, m,
-                           kh * kw * (cin // 32), 2 * m * cout * cin * kh * kw, amax)
+        if chain is not None and not projection_ok():
+            chain = None
+        r = _conv_split(x, pk, out, (n, h, w), (1, kh, kw), (1, sh, sw), (0, ph, pw), False, residual, residual_up2, relu, splits, tile, m,
+                        kh * kw * (cin // 32), 2 * m * cout * cin * kh * kw, amax, chain)
+        return r if (not pair or isinstance(r, tuple)) else (r, None)
     tile, splits = choose_tiling(m, cout, kh * kw * (cin // 32), tile, splits)
     ws = torch.empty((m * cout * splits * 4,), dtype=torch.uint8, device=x.device) if splits > 1 else None
     i3 = lambda a, b, c: (ctypes.c_int * 3)(a, b, c)
@@ -600,7 +625,7 @@ def conv2d_nhwc(x: torch.Tensor, pk: dict, residual: Optional[torch.Tensor] = No
             lambda: check(lib.ndet_conv_ndhwc(_ptr(x), _ptr(pk["w"]), _ptr(out), n, h, w, cin, cout, i3(1, kh, kw), i3(1, sh, sw), i3(0, ph, pw),
                                               _ptr(pk["scale"]), _ptr(pk["shift"]), _ptr(residual), int(residual_up2), relu, splits, tile, _ptr(ws), st),
                           "conv2d_nhwc"), "f32", tile, 4 * (x.numel() + pk["w"].numel() + out.numel() + (0 if residual is None else residual.numel())))
-    return out
+    return (out, None) if pair else out
 
 
 CHAIN_BOTTLENECKS = True    # conv2 -> conv3 of the 64- / 128-channel bottlenecks in one launch (k_conv_split_chain)

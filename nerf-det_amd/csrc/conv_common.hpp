@@ -45,6 +45,13 @@ struct Conv3dParams {
     int nt = 0;                       // 1: the output is written with non-temporal stores (set by the launcher for outputs that cannot stay in the caches)
     float* amax_out = nullptr;        // any arithmetic, optional: max |out| is atomically maxed into the slot at amax_out (1 KiB, zeroed by the caller
                                       // before the launch) -- the next layer's amax_in without another pass over the tensor
+    // chained 1x1 projection of the finished rows (halo tiles that own all Cout channels of their rows; conv_map_rows below): the detector's 256 -> 32
+    // feature mapping (mmdet3d/models/detectors/nerfdet.py:194-197) behind the FPN output convolution, so that the 276 MB feature map is not read
+    // back by a launch of its own.  map_w: (Cout, 32) floats = scale_c * Wm[j][c]; map_b: (32) = sum_c shift_c Wm[j][c] + bm[j] (the convolution's own
+    // affine folded in on the host: no ReLU / residual on such a launch); map_out: (M, 32) floats
+    const float* map_w = nullptr;
+    const float* map_b = nullptr;
+    float* map_out = nullptr;
     // range guard of the fp16-pair arithmetic (conv_guard_check below)
     unsigned* guard = nullptr;        // device word, bit 0 raised when this launch's absolute error floor exceeds guard_tol (null: no check)
     float guard_l1 = 0.0f;            // max over output channels j of |scale_j| (sum_k |w_jk| + wmax #{k: 0 < |w_jk| < 2^-16 wmax})
@@ -265,5 +272,59 @@ __device__ __forceinline__ void conv_store_rows(const Conv3dParams& p, const flo
                                                 int ztap, int zsplit, float& mx, float osc) {
     conv_store_rows_mapped<BN, NTHR>(p, Cs, cld, rows, n0, tid, ztap, zsplit, ConvLinearRows{m_first}, mx, osc);
 }
+// Chained 1x1 projection of 64 tile rows staged in LDS (raw accumulators, as conv_store_rows_mapped reads them): out[m][j] = osc * sum_c Cs[row][c] *
+// Wl[c][j] + map_b[j], 32 outputs per row, fp32 FMAs (exact-operand arithmetic, whatever the convolution ran in).  Wl: the (BN, 32) weight in LDS.
+// 512 threads: a thread owns 4 rows x 4 outputs over a QUARTER of the channels (5 LDS reads per 16 FMAs; one output pair per thread over all
+// channels was LDS-issue bound: +90 us on the FPN output convolution, as much as the separate launch it replaces); the four partial sums per
+// output meet in LDS -- in the rows' own staging area, which is dead by then -- and are added in a fixed order.  Three barriers inside: every
+// thread of the workgroup must call.
+template <int BN, int NTHR, typename RowMap>
+__device__ __forceinline__ void conv_map_rows(const Conv3dParams& p, float* Cs, int cld, int tid, RowMap m_of, float osc, const float* Wl) {
+    static_assert(BN % 4 == 0 && NTHR >= 512, "conv_map_rows: 512 threads, BN a multiple of 4");
+    constexpr int KQ = BN / 4;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    const int kq = tid >> 7, rg = (tid >> 3) & 15, jg = tid & 7;     // channel quarter, row group (rows rg + 16 i), output quad
+    if (tid < 512) {
+        const float* c = Cs + rg * cld + kq * KQ;
+        const float* w = Wl + (kq * KQ) * 32 + 4 * jg;
+#pragma unroll 2
+        for (int k = 0; k < KQ; ++k) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + k * 32);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = c[(16 * i) * cld + k];
+                acc[i][0] = fmaf(v, wv.x, acc[i][0]); acc[i][1] = fmaf(v, wv.y, acc[i][1]);
+                acc[i][2] = fmaf(v, wv.z, acc[i][2]); acc[i][3] = fmaf(v, wv.w, acc[i][3]);
+            }
+        }
+    }
+    __syncthreads();                                   // every reader of the staged rows is done: the partial sums take their place
+    float* P = Cs;                                     // [4 quarters][64 rows][32]
+    if (tid < 512) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(P + ((kq * 64 + rg + 16 * i) * 32 + 4 * jg)) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    }
+    __syncthreads();
+    for (int o = tid; o < 64 * 8; o += NTHR) {         // a float4 of one row's outputs per thread
+        const int row = o >> 3, j4 = o & 7;
+        const int m = m_of(row);
+        if (m < 0 || m >= p.M) continue;
+        float4 t = *reinterpret_cast<const float4*>(P + (row * 32 + 4 * j4));
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float4 u = *reinterpret_cast<const float4*>(P + ((q * 64 + row) * 32 + 4 * j4));
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        const float4 b = *reinterpret_cast<const float4*>(p.map_b + 4 * j4);
+        *reinterpret_cast<float4*>(p.map_out + (int64_t)m * 32 + 4 * j4) = make_float4(fmaf(t.x, osc, b.x), fmaf(t.y, osc, b.y), fmaf(t.z, osc, b.z), fmaf(t.w, osc, b.w));
+    }
+    __syncthreads();                                   // the staging area is free for the next half's rows
+}
+
 // does this launch's epilogue write the layer's final values (split-K launches write partials: their reduce pass commits the maximum)
 __device__ __forceinline__ bool conv_writes_final(const Conv3dParams& p) { return p.transposed || p.splits <= 1; }

@@ -1621,8 +1621,14 @@ __global__ __launch_bounds__(64 * (2 * WGN + NPROD), 1) void k_conv_split_halo(c
                         Cs[(ta * 16 + (lane >> 4) * 4 + r) * CLDC + wn * (16 * NT16) + tb * 16 + (lane & 15)] = acc[ta][tb][r];
         }
         __syncthreads();
-        conv_store_rows_mapped<BN, NTHR>(p, Cs, CLDC, 64, n0, tid, 0, blk.z, HaloRowMap{h * 64, g.ltw, g.lth, d0, h0, w0, p.OD, p.OH, p.OW}, mx, conv_oscale_of(p, amax_in));
-        __syncthreads();
+        const HaloRowMap rmap{h * 64, g.ltw, g.lth, d0, h0, w0, p.OD, p.OH, p.OW};
+        const float osc = conv_oscale_of(p, amax_in);
+        float* Wl = Cs + 64 * CLDC;                     // (BN, 32) floats behind the staged rows (the launcher checked the room)
+        if (p.map_out && h == 0)                        // every wave has left the K walk (the barrier above): the operand stages are free
+            for (int i = tid; i < BN * 8; i += NTHR) reinterpret_cast<float4*>(Wl)[i] = reinterpret_cast<const float4*>(p.map_w)[i];
+        conv_store_rows_mapped<BN, NTHR>(p, Cs, CLDC, 64, n0, tid, 0, blk.z, rmap, mx, osc);
+        __syncthreads();                                // (and Wl is in place)
+        if (p.map_out) conv_map_rows<BN, NTHR>(p, Cs, CLDC, tid, rmap, osc, Wl);      // (uniform branch; barriers inside)
     }
     if (p.amax_out && conv_writes_final(p)) conv_amax_commit(p.amax_out, mx);
 }
@@ -1669,9 +1675,16 @@ static int split_launch_halo(const Conv3dParams& p, hipStream_t st, const char* 
     size_t lds = (size_t)(NPL * HALO_MAX * CBK + NSTAGE * NPL * BN * CBK) * sizeof(uint16_t);
     const size_t cs = (size_t)64 * (BN + 4) * sizeof(float);
     if (cs > lds) lds = cs;
+    const size_t lds_map = cs + (size_t)BN * 32 * sizeof(float);     // the staged rows + the chained projection's (BN, 32) weight
+    const size_t lds_cap = lds_map > lds ? lds_map : lds;
+    if (p.map_out) {
+        NDET_REQUIRE(p.Cout == BN && p.splits == 1 && !p.res && p.relu == 0, NDET_E_UNSUPPORTED,
+                     "%s: the chained projection needs a tile that owns all %d output channels of its rows, no split-K / residual / ReLU", fn, p.Cout);
+        lds = lds_cap;
+    }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_conv_split_halo<NT16, WGN, SCH, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_conv_split_halo<NT16, WGN, SCH, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
         NDET_REQUIRE(e == hipSuccess, NDET_E_LAUNCH, "%s: cannot raise the LDS limit: %s", fn, hipGetErrorString(e));
         attr_set = true;
     }
@@ -2036,8 +2049,8 @@ extern "C" int ndet_conv_ndhwc_bf16(const float* in, const uint16_t* w_planes, f
                             residual_up2, relu, splits, tile, workspace, stream);
 }
 
-struct ConvGuard { unsigned* flag; float l1, l1_3, tol; const float* w_amax; };
-static thread_local ConvGuard g_guard = {nullptr, 0.0f, 0.0f, 0.0f, nullptr};     // handed from the *_guarded / *_train entry points to the shared argument checks below (per call)
+struct ConvGuard { unsigned* flag; float l1, l1_3, tol; const float* w_amax; const float* map_w; const float* map_b; float* map_out; };
+static thread_local ConvGuard g_guard = {nullptr, 0.0f, 0.0f, 0.0f, nullptr, nullptr, nullptr, nullptr};     // handed from the *_guarded / *_train entry points to the shared argument checks below (per call)
 
 extern "C" int ndet_conv_ndhwc_guarded(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
                                        const int* kernel, const int* stride, const int* pad, int transposed, const float* scale,
@@ -2049,6 +2062,25 @@ extern "C" int ndet_conv_ndhwc_guarded(const float* in, const uint16_t* w_planes
     const int rc = ndet_conv_ndhwc_arith(in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, transposed, scale, shift, residual, residual_up2, relu, splits,
                                          tile, arith, in_amax, w_inv_scale, out_amax, workspace, stream);
     g_guard = ConvGuard{nullptr, 0.0f, 0.0f, 0.0f, nullptr};
+    return rc;
+}
+
+// ndet_conv_ndhwc_guarded with a chained 32-channel projection of the output rows in the same launch (see Conv3dParams::map_out): only the
+// halo-stationary tiles that own all Cout = 256 channels of their rows take it (tile 3256 / 3257 / 3258), without split-K, residual or ReLU.
+extern "C" int ndet_conv_ndhwc_mapped(const float* in, const uint16_t* w_planes, float* out, int D, int H, int W, int Cin, int Cout,
+                                      const int* kernel, const int* stride, const int* pad, const float* scale, const float* shift, int tile, int arith,
+                                      const float* in_amax, float w_inv_scale, float* out_amax, float guard_l1, float guard_tol, unsigned* guard,
+                                      const float* map_w, const float* map_b, float* map_out, void* stream) {
+    const char* fn = "ndet_conv_ndhwc_mapped";
+    NDET_REQUIRE(map_w && map_b && map_out, NDET_E_INVALID, "%s: null projection pointers", fn);
+    NDET_REQUIRE((((uintptr_t)map_w | (uintptr_t)map_b | (uintptr_t)map_out) & 15) == 0, NDET_E_UNSUPPORTED, "%s: projection pointers must be 16-byte aligned", fn);
+    NDET_REQUIRE(tile == 3256 || tile == 3257 || tile == 3258, NDET_E_UNSUPPORTED, "%s: tile %d does not own whole rows (3256 / 3257 / 3258 do)", fn, tile);
+    NDET_REQUIRE(Cout == 256, NDET_E_UNSUPPORTED, "%s: Cout=%d, the 256-column tiles own whole rows of 256 channels only", fn, Cout);
+    NDET_REQUIRE(!guard || (guard_l1 >= 0.0f && guard_tol > 0.0f), NDET_E_INVALID, "%s: the guard needs guard_l1 >= 0 and guard_tol > 0", fn);
+    g_guard = ConvGuard{arith == 1 ? guard : nullptr, guard_l1, 0.0f, guard_tol, nullptr, map_w, map_b, map_out};
+    const int rc = ndet_conv_ndhwc_arith(in, w_planes, out, D, H, W, Cin, Cout, kernel, stride, pad, 0, scale, shift, nullptr, 0, 0, 1, tile, arith, in_amax, w_inv_scale,
+                                         out_amax, nullptr, stream);
+    g_guard = ConvGuard{nullptr, 0.0f, 0.0f, 0.0f, nullptr, nullptr, nullptr, nullptr};
     return rc;
 }
 
@@ -2133,6 +2165,7 @@ static int conv_split_entry(const char* fn, int max_order, const float* in_amax,
     p.max_order = max_order;
     p.amax_in = in_amax; p.winv = w_inv_scale; p.amax_out = out_amax;
     p.guard = g_guard.flag; p.guard_l1 = g_guard.l1; p.guard_tol = g_guard.tol; p.w_amax = g_guard.w_amax;
+    p.map_w = g_guard.map_w; p.map_b = g_guard.map_b; p.map_out = g_guard.map_out;
     if (transposed) {
         for (int a = 0; a < 3; ++a)
             NDET_REQUIRE(kernel[a] == 2 && stride[a] == 2 && pad[a] == 0, NDET_E_UNSUPPORTED, "%s: transposed conv supports kernel 2 stride 2 pad 0 only", fn);

@@ -83,6 +83,10 @@ class nerfdet(BaseDetector):
         self.cov_mapping = nn.Sequential(nn.Conv3d(c, fd // 2, 1))
         self.mapping = nn.Sequential(nn.Linear(c, fd // 2))
         self.mapping_2d = nn.Sequential(nn.Conv2d(c, fd // 2, 1))
+        if hasattr(self.neck, "forward_hip") and "chain_linear" in self.neck.__dict__:
+            # inference: the level-0 output convolution of the FPN projects its rows through self.mapping in the same launch (backbone.FPN.forward_hip);
+            # through __dict__: the Linear must not become a submodule of the neck (state-dict keys)
+            self.neck.__dict__["chain_linear"] = self.mapping[0]
         self.init_weights(pretrained=pretrained)
         # MI355X: 2D convs run channels-last (MIOpen NHWC), so FPN level 0 arrives in the layout the
         # gather kernels want; only FPN output 0 is consumed (nerfdet.py:142)
@@ -132,14 +136,17 @@ class nerfdet(BaseDetector):
         if not torch.is_grad_enabled():
             geoms = [scene_geometry(m, self.n_voxels, self.voxel_size, stride, img.device) for m in img_metas]
         n_v = x.shape[0] // batch
+        f2d = getattr(x, "_ndet_feature_2d", None)        # the mapped map, when the FPN's output convolution produced it on the way (inference)
         denorm = ray_batch["denorm_images"]
         volumes, valids, rgb_preds = [], [], []
         for b, img_meta in enumerate(img_metas):
             feat = x[b * n_v:(b + 1) * n_v]
             dn = denorm.reshape([-1] + list(denorm.shape)[2:])
             # channels-last volume straight into the MFMA convolutions of the 3D neck (inference and training alike)
+            hf, wf = img_meta["img_shape"][0] // stride, img_meta["img_shape"][1] // stride
             out = extract_volume(feat, dn, img_meta, self.n_voxels, self.voxel_size, self.mapping, self.nerf_mlp,
                                  stride=stride, channels_last_out=True,
+                                 feature_2d=None if (f2d is None or torch.is_grad_enabled()) else f2d[b * n_v:(b + 1) * n_v, :, :hf, :wf],
                                  geometry=None if geoms is None else geoms[b])
             if mode == "train" or self.render_testing:
                 from .rays import render_rays

@@ -604,3 +604,35 @@ def test_whole_bottleneck_in_one_launch(device, inplanes, nhw):
     assert fused.shape == ref.shape
     assert float((fused.cpu().double() - ref).abs().max()) <= 2e-5 * scale
     assert e_fused < 1e-6 and e_fused <= 1.15 * e_two, (e_fused, e_two)
+
+
+@pytest.mark.parametrize("tile", [3256, 3257, 3258])
+@pytest.mark.parametrize("nhw", [(2, 24, 40), (3, 13, 21)])
+def test_chained_projection_in_the_halo_epilogue(device, tile, nhw):
+    """conv2d_nhwc(..., chain=...): the detector's 256 -> 32 feature mapping (mmdet3d/models/detectors/nerfdet.py:194-197) computed in the FPN output
+    convolution's epilogue (csrc/conv_common.hpp::conv_map_rows) against the two separate modules in fp64, on every 256-column halo tile, with
+    patches that hang over the map's edges; the convolution's own output must be what the plain launch writes, bit for bit."""
+    from torch import nn
+    import nerfdet_amd.conv3d as C
+    from nerfdet_amd.backbone import _chain_pack
+    if not C.projection_ok():
+        pytest.skip("the chained projection belongs to the fp16-pair mode")
+    torch.manual_seed(tile + nhw[1])
+    conv = nn.Conv2d(256, 256, 3, 1, 1).to(device)
+    lin = nn.Linear(256, 32).to(device)
+    with torch.no_grad():
+        conv.bias.normal_(0, 0.5)
+        lin.bias.normal_(0, 0.3)
+    x = torch.randn(*nhw, 256, device=device)
+    pk = C.packed([conv])
+    plain = C.conv2d_nhwc(x, pk, amax=False, tile=tile, splits=1)
+    out, mapped = C.conv2d_nhwc(x, pk, amax=False, tile=tile, splits=1, chain=_chain_pack(pk, lin))
+    assert mapped is not None and mapped.shape == (nhw[0] * nhw[1] * nhw[2], 32)
+    assert torch.equal(out, plain)
+    ref_o = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), conv.weight.double(), conv.bias.double(), padding=1).permute(0, 2, 3, 1)
+    ref_m = torch.nn.functional.linear(ref_o, lin.weight.double(), lin.bias.double()).reshape(-1, 32)
+    err = float((mapped.double() - ref_m).abs().max()) / float(ref_m.abs().max())
+    assert err <= 2e-5, err
+    # a tile that does not own whole rows hands the projection back to the caller
+    o2, m2 = C.conv2d_nhwc(x, pk, amax=False, tile=128, chain=_chain_pack(pk, lin))
+    assert m2 is None and torch.equal(o2, C.conv2d_nhwc(x, pk, amax=False, tile=128))
