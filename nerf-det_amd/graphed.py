@@ -31,8 +31,11 @@ class GraphedForwardTest:
     def _front(self):
         det = self.det
         x, b, stride = det.extract_2d(self.img)
+        f2d = getattr(x, "_ndet_feature_2d", None)         # the mapped map, when the FPN's output convolution produced it on the way
+        if f2d is not None:
+            f2d = f2d[:, :, :self.meta["img_shape"][0] // stride, :self.meta["img_shape"][1] // stride]
         return density_alpha(x, self.denorm[0], self.meta, det.n_voxels, det.voxel_size, det.mapping, det.nerf_mlp, stride=stride,
-                             geometry=self.geom)
+                             feature_2d=f2d, geometry=self.geom)
 
     def _k1(self):
         d = self.d
