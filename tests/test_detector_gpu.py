@@ -504,3 +504,46 @@ def test_checkpoint_loaded_after_a_warm_forward_takes_effect_and_round_trips(dev
     load_checkpoint(det_c, path_a, map_location="cpu", strict=True)
     res_c = run(det_c)
     assert torch.equal(res_c["scores_3d"], res_b["scores_3d"]) and torch.equal(res_c["boxes_3d"].tensor, res_b["boxes_3d"].tensor)
+
+
+def test_all_levels_decoded_in_one_launch_equal_the_per_level_launches(device):
+    """ndet_head_decode_levels against ndet_level_valid + ndet_head_decode level by level (imvoxel_head_v2.py:262-271,442-449,547-555): the same
+    scores, labels and boxes bit for bit, on three levels of a 16 x 12 x 8 grid with a ragged validity volume."""
+    import ctypes
+    from ctypes import c_void_p
+    import numpy as np
+    from nerfdet_amd import _lib
+    from nerfdet_amd._lib import check, float3
+    lib = _lib.load()
+    torch.manual_seed(3)
+    X, Y, Z, ncls = 16, 12, 8, 18
+    valid = (torch.rand(X, Y, Z, device=device) > 0.35).float().contiguous()
+    st = c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    vs0, origin = np.float32([0.16, 0.16, 0.2]), np.float32([0.3, -0.2, 1.1])
+    raws, scales, grids, facs = [], [], [], []
+    for l in range(3):
+        f = 2 ** l
+        g = (X // f, Y // f, Z // f)
+        raws.append(torch.randn(*g, 7 + ncls, device=device))
+        scales.append(torch.tensor([0.7 + 0.2 * l], device=device))
+        grids.append(g)
+        facs.append(f)
+    ref = []
+    for l, (raw, sc, g, f) in enumerate(zip(raws, scales, grids, facs)):
+        n = g[0] * g[1] * g[2]
+        v = torch.empty(n, dtype=torch.uint8, device=device)
+        check(lib.ndet_level_valid(c_void_p(valid.data_ptr()), X, Y, Z, f, c_void_p(v.data_ptr()), st), "level_valid")
+        best, lab, box = torch.empty(n, device=device), torch.empty(n, dtype=torch.int64, device=device), torch.empty(n, 6, device=device)
+        check(lib.ndet_head_decode(c_void_p(raw.data_ptr()), ncls, c_void_p(v.data_ptr()), c_void_p(sc.data_ptr()), *g, float3(np.float32(vs0 * f)), float3(origin),
+                                   c_void_p(best.data_ptr()), c_void_p(lab.data_ptr()), c_void_p(box.data_ptr()), st), "head_decode")
+        ref.append((best, lab, box))
+    outs = [(torch.empty(g[0] * g[1] * g[2], device=device), torch.empty(g[0] * g[1] * g[2], dtype=torch.int64, device=device),
+             torch.empty(g[0] * g[1] * g[2], 6, device=device)) for g in grids]
+    vp = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    vsz = np.concatenate([np.float32(vs0 * f) for f in facs]).astype(np.float32)
+    check(lib.ndet_head_decode_levels(3, vp(raws), vp(scales), (ctypes.c_int * 9)(*[v for g in grids for v in g]), (ctypes.c_int * 3)(*facs),
+                                      vsz.ctypes.data_as(c_void_p), origin.ctypes.data_as(c_void_p), ncls, c_void_p(valid.data_ptr()), X, Y, Z,
+                                      vp([o[0] for o in outs]), vp([o[1] for o in outs]), vp([o[2] for o in outs]), st), "head_decode_levels")
+    for (b0, l0, x0), (b1, l1, x1) in zip(ref, outs):
+        assert torch.equal(b0, b1) and torch.equal(l0, l1) and torch.equal(x0, x1)
+    assert float(ref[0][0].max()) > 0 and int((ref[1][0] == 0).sum()) > 0       # some voxels valid, some masked

@@ -175,3 +175,36 @@ def test_depth_rays_from_the_loader_replace_the_device_nonzero():
     # the pipeline's collector passes the key on whenever it passes the depth maps
     out = Collect3D(keys=["gt_depths"])(dict(gt_depths=scene["gt_depths"][0], depth_rays=scene["depth_rays"][0]))
     assert "depth_rays" in out and "depth_rays" not in Collect3D(keys=["img"])(dict(img=0, depth_rays=1))
+
+
+def test_linear_rows_splits_the_weight_gradient_without_changing_it():
+    """autograd.LinearRows (the radiance MLP's Linear layers over 131 072 rows, the 192 000-row feature mapping): the weight gradient formed chunk by
+    chunk with one batched GEMM, the bias gradient in two stages, the ReLU mask applied once -- against autograd's own Linear (+ ReLU) in fp64, for
+    row counts that do and do not divide into chunks, with and without bias / ReLU, and a leading batch axis."""
+    import torch
+    import nerfdet_amd.autograd as A
+    torch.manual_seed(0)
+    keep = A.LINEAR_SPLIT_ROWS
+    A.LINEAR_SPLIT_ROWS = 1024
+    try:
+        for n, ci, co, relu, bias in [(4096 * 3, 37, 16, True, True), (8192, 64, 3, False, True), (6000, 32, 8, True, False), (100, 5, 4, True, True)]:
+            x = torch.randn(2, n // 2, ci, dtype=torch.float64, requires_grad=True)
+            w = torch.randn(co, ci, dtype=torch.float64, requires_grad=True)
+            b = torch.randn(co, dtype=torch.float64, requires_grad=True) if bias else None
+            y = A.LinearRows.apply(x, w, b, relu)
+            gy = torch.randn_like(y)
+            y.backward(gy)
+            got = [x.grad.clone(), w.grad.clone(), None if b is None else b.grad.clone()]
+            x.grad = w.grad = None
+            if b is not None:
+                b.grad = None
+            ref = torch.nn.functional.linear(x, w, b)
+            ref = torch.relu(ref) if relu else ref
+            ref.backward(gy)
+            assert A._split_rows(n) >= 1 and n % A._split_rows(n) == 0
+            assert torch.equal(y, ref) and torch.equal(got[0], x.grad)
+            assert float((got[1] - w.grad).abs().max()) <= 1e-11 * max(1.0, float(w.grad.abs().max()))
+            if b is not None:
+                assert float((got[2] - b.grad).abs().max()) <= 1e-11 * max(1.0, float(b.grad.abs().max()))
+    finally:
+        A.LINEAR_SPLIT_ROWS = keep
