@@ -274,21 +274,22 @@ __device__ __forceinline__ void conv_store_rows(const Conv3dParams& p, const flo
 }
 // Chained 1x1 projection of 64 tile rows staged in LDS (raw accumulators, as conv_store_rows_mapped reads them): out[m][j] = osc * sum_c Cs[row][c] *
 // Wl[c][j] + map_b[j], 32 outputs per row, fp32 FMAs (exact-operand arithmetic, whatever the convolution ran in).  Wl: the (BN, 32) weight in LDS.
-// 512 threads: a thread owns 4 rows x 4 outputs over a QUARTER of the channels (5 LDS reads per 16 FMAs; one output pair per thread over all
-// channels was LDS-issue bound: +90 us on the FPN output convolution, as much as the separate launch it replaces); the four partial sums per
+// A thread owns 4 rows x 4 outputs over a SLICE of the channels (a quarter, or an eighth where the tile has 1 024 threads; 5 LDS reads per 16 FMAs; one output pair per thread over all
+// channels was LDS-issue bound: +90 us on the FPN output convolution, as much as the separate launch it replaces); the slices' partial sums per
 // output meet in LDS -- in the rows' own staging area, which is dead by then -- and are added in a fixed order.  Three barriers inside: every
 // thread of the workgroup must call.
 template <int BN, int NTHR, typename RowMap>
 __device__ __forceinline__ void conv_map_rows(const Conv3dParams& p, float* Cs, int cld, int tid, RowMap m_of, float osc, const float* Wl) {
-    static_assert(BN % 4 == 0 && NTHR >= 512, "conv_map_rows: 512 threads, BN a multiple of 4");
-    constexpr int KQ = BN / 4;
+    constexpr int KS = NTHR >= 1024 ? 8 : 4;           // channel slices = 128-thread groups at work (all 16 waves of the eight-producer tile)
+    static_assert(BN % KS == 0 && NTHR >= 128 * KS, "conv_map_rows: 128 threads per channel slice");
+    constexpr int KQ = BN / KS;
     float acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    const int kq = tid >> 7, rg = (tid >> 3) & 15, jg = tid & 7;     // channel quarter, row group (rows rg + 16 i), output quad
-    if (tid < 512) {
+    const int kq = tid >> 7, rg = (tid >> 3) & 15, jg = tid & 7;     // channel slice, row group (rows rg + 16 i), output quad
+    if (tid < 128 * KS) {
         const float* c = Cs + rg * cld + kq * KQ;
         const float* w = Wl + (kq * KQ) * 32 + 4 * jg;
 #pragma unroll 2
@@ -303,8 +304,8 @@ __device__ __forceinline__ void conv_map_rows(const Conv3dParams& p, float* Cs, 
         }
     }
     __syncthreads();                                   // every reader of the staged rows is done: the partial sums take their place
-    float* P = Cs;                                     // [4 quarters][64 rows][32]
-    if (tid < 512) {
+    float* P = Cs;                                     // [KS slices][64 rows][32]  (KS * 8 KB <= the rows' 65 KB)
+    if (tid < 128 * KS) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             *reinterpret_cast<float4*>(P + ((kq * 64 + rg + 16 * i) * 32 + 4 * jg)) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
@@ -316,7 +317,7 @@ __device__ __forceinline__ void conv_map_rows(const Conv3dParams& p, float* Cs, 
         if (m < 0 || m >= p.M) continue;
         float4 t = *reinterpret_cast<const float4*>(P + (row * 32 + 4 * j4));
 #pragma unroll
-        for (int q = 1; q < 4; ++q) {
+        for (int q = 1; q < KS; ++q) {
             const float4 u = *reinterpret_cast<const float4*>(P + ((q * 64 + row) * 32 + 4 * j4));
             t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
         }
