@@ -62,8 +62,23 @@ def prepare_step(module: nn.Module) -> int:
         block = C.AMAX.take_many(ws[0].device, len(ws))
         block[:, 0] = torch.stack(norms)
     for i, w in enumerate(ws):
-        _STEP_SLOTS[(w.data_ptr(), w._version)] = block[i]
+        # with a weak reference to the parameter itself: an entry outlives its step (a caller may run forward / backward without coming through
+        # train_one_step), and a NEW model's weight can land on a freed one's address with the same version count -- found by a test that built a
+        # second model after a first had trained: stale maxima, wrong scales, NaN gradients.  A freed parameter's reference is dead; a live one
+        # cannot share its address with another tensor.
+        _STEP_SLOTS[(w.data_ptr(), w._version)] = (weakref.ref(w), block[i])
     return len(ws)
+
+
+def _step_slot(w: Tensor):
+    """The amax slot prepare_step left for the parameter behind ``w`` (a detached alias of it), or None."""
+    hit = _STEP_SLOTS.get((w.data_ptr(), w._version))
+    if hit is None:
+        return None
+    owner = hit[0]()
+    if owner is None or owner.data_ptr() != w.data_ptr() or owner._version != w._version or owner.shape != w.shape:
+        return None
+    return hit[1]
 
 
 def _split_both(w: Tensor, taps: int, arith: str, want_adjoint: bool):
@@ -80,7 +95,7 @@ def _split_both(w: Tensor, taps: int, arith: str, want_adjoint: bool):
     st = c_void_p(raw_stream(w.device))
     slot = None
     if arith == "f16x2":
-        slot = _STEP_SLOTS.get((w.data_ptr(), w._version))
+        slot = _step_slot(w)
         if slot is None:
             slot = C.AMAX.take(w.device)
             _lib.check(_lib.load().ndet_amax_f32(c_void_p(wc.data_ptr()), wc.numel(), c_void_p(slot.data_ptr()), st), "amax_f32")

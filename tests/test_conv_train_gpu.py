@@ -282,12 +282,24 @@ def test_prepare_step_hands_every_convolution_weight_its_maximum(device, train_a
         return
     assert n == 2
     for m in (net[0], net[2]):
-        slot = conv_train._STEP_SLOTS[(m.weight.data_ptr(), m.weight._version)]
-        assert amax_value(slot) == float(m.weight.abs().max())
+        slot = conv_train._step_slot(m.weight.detach())
+        assert slot is not None and amax_value(slot) == float(m.weight.abs().max())
     _, _, slot = conv_train._split_both(net[0].weight.detach(), 27, "f16x2", False)
-    assert slot.data_ptr() == conv_train._STEP_SLOTS[(net[0].weight.data_ptr(), net[0].weight._version)].data_ptr()
+    assert slot.data_ptr() == conv_train._step_slot(net[0].weight.detach()).data_ptr()
     with torch.no_grad():
         net[0].weight.mul_(2.0)                               # the optimizer moved it: the old slot no longer applies
     _, _, slot2 = conv_train._split_both(net[0].weight.detach(), 27, "f16x2", False)
     assert slot2.data_ptr() != slot.data_ptr() and amax_value(slot2) == float(net[0].weight.abs().max())
     conv_train.prepare_step(net)
+    # a model that is gone must not lend its maxima to a new one whose weights land on the freed addresses (same shapes, same version counts)
+    shapes = [(m.weight.data_ptr(), m.weight._version) for m in (net[0], net[2])]
+    del net, m, slot, slot2
+    import gc
+    gc.collect()
+    torch.manual_seed(6)
+    net2 = nn.Sequential(nn.Conv3d(32, 64, 3, 1, 1), nn.Conv2d(64, 32, 1), nn.ConvTranspose3d(64, 32, 2, 2), nn.Linear(8, 8)).to(device)
+    with torch.no_grad():
+        net2[0].weight.mul_(100.0)
+    reused = (net2[0].weight.data_ptr(), net2[0].weight._version) in shapes
+    _, _, slot3 = conv_train._split_both(net2[0].weight.detach(), 27, "f16x2", False)
+    assert amax_value(slot3) == float(net2[0].weight.abs().max()), ("stale slot", reused)
