@@ -28,7 +28,8 @@ from ._lib import raw_stream
 # accumulated in fp32: half the matrix-core work of bf16x3 at the same or a smaller measured error against fp64 (three accumulator
 # roundings per K step instead of six; tests/test_conv3d_gpu.py::test_f16x2_error_not_above_bf16x3).  The activation scale is derived on the
 # device from the input's max |x|, which every convolution epilogue leaves behind for the next layer (the `_ndet_amax` attribute of its output
-# tensor); layers with fewer than F16_MIN_KSTEPS K steps stay on bf16x3 (HBM-bound: nothing to gain), training stays on bf16x3.
+# tensor); layers with fewer than F16_MIN_KSTEPS K steps stay on bf16x3 (HBM-bound: nothing to gain); training follows it with
+# every scale taken on the device (TRAIN_F16X2 below, conv_train.py).
 ARITHMETIC = "f16x2"
 F16_MIN_KSTEPS = 4
 SPLIT_FAMILY = ("bf16x3", "bf16", "f16x2")    # the arithmetics of csrc/conv_split_kernels.hip
